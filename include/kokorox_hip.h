@@ -1,0 +1,148 @@
+/*
+ * kokorox_hip.h — C ABI of libkokorox_hip.so: the MI355X-native replacement for the one
+ * hot path of byteowlz/kokorox, the Kokoro-82M forward pass that the reference runs as
+ * `ort::Session::run()` inside `OrtKoko::infer`.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference checkout).  Plain pointers and sizes only; no C++/torch types; nothing
+ * throws or unwinds across this boundary: every call returns a status and the text of
+ * the last failure is available from kx_last_error().
+ *
+ * Threading: a kx_model may be shared by any number of OS threads.  Calls on one model
+ * are serialised on an internal mutex, which is exactly what the reference's
+ * `Mutex<Session>` does (kokorox/src/onn/ort_koko.rs:14,78).  Use one model per GPU.
+ */
+#ifndef KOKOROX_HIP_H
+#define KOKOROX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KX_OK 0
+#define KX_ERR_INVALID 1   /* bad argument (empty batch, id out of range, T > 512 ...)   */
+#define KX_ERR_IO 2        /* weight file missing / malformed                             */
+#define KX_ERR_DEVICE 3    /* HIP runtime failure, no gfx950 device                       */
+#define KX_ERR_STATE 4     /* unknown tap name, profiling not enabled ...                 */
+
+#define KX_STYLE_DIM 256       /* ort_koko.rs:44 "1,256"; koko.rs:1255-1306 builds the row */
+#define KX_SAMPLES_PER_FRAME 600
+#define KX_SAMPLE_RATE 24000
+#define KX_MAX_TOKENS 512      /* model position table; koko.rs:783 chunks to <=500 + 2 pads */
+
+/* kx_infer flags */
+#define KX_FLAG_NOISE_OFF 1u   /* zero the SineGen additive noise (timing experiments only) */
+#define KX_FLAG_TAPS 2u        /* keep named intermediates for kx_debug_tap (tests)          */
+
+typedef struct kx_model kx_model;
+
+/* Replaces `init_ort(dylib_path)` (kokorox/src/onn/mod.rs:19-49): one-off runtime
+ * initialisation.  Checks that `device_id` exists and is a gfx950 part.
+ * err/err_len: optional buffer for a message when the return value is not KX_OK. */
+int kx_init(int device_id, char* err, size_t err_len);
+
+/* Replaces `OrtKoko::new(model_path)` → `OrtBase::load_model`
+ * (kokorox/src/onn/ort_koko.rs:31-35, ort_base.rs:14-39): reads a KXHIPW01 weight file
+ * (kokorox_amd/weights.py), uploads it, repacks the contraction weights for the MFMA
+ * kernels.  Returns NULL on failure with the reason in err. */
+kx_model* kx_create(const char* weights_path, int device_id, char* err, size_t err_len);
+
+/* Same, from a weight blob that is ALREADY resident in this GPU's memory, e.g. after the
+ * one-time RCCL broadcast over xGMI.  The blob is borrowed for the
+ * duration of the call only (the library keeps its own repacked copy and copies the
+ * small tensors it needs). */
+kx_model* kx_create_from_device_blob(const void* d_blob, size_t n_bytes, int device_id,
+                                     char* err, size_t err_len);
+
+/* Replaces `Drop for OrtKoko` / TTSKoko::cleanup (kokorox/src/tts/koko.rs:1338-1375). */
+void kx_destroy(kx_model* m);
+
+/* Text of the last failure on this model ("" if none).  Valid until the next call. */
+const char* kx_last_error(const kx_model* m);
+
+/* Replaces `OrtKoko::infer(tokens, styles, speed)` (kokorox/src/onn/ort_koko.rs:37-91;
+ * caller kokorox/src/tts/koko.rs:1177).
+ *   ids      [B, t_stride] int64, row b holds lens[b] token ids already wrapped with the
+ *            0 pad at both ends (koko.rs:1169-1173); ids must be in 0..177 (vocab.rs:5-20)
+ *   lens     [B] tokens per utterance incl. the two pads, 3..512.  The reference is
+ *            batch-1 (koko.rs:1175); B>1 gives the same result as B separate calls.
+ *   styles   [B,256] float32 voice-style rows (mix_styles, koko.rs:1255-1306)
+ *   speeds   [n_speed] float32, n_speed = 1 (shared, ort_koko.rs:67-68) or B
+ *   seed     Philox key of the harmonic-source noise; utterance b of the call draws the
+ *            stream (seed, utt_base + b)
+ *   out      *out = malloc'd float32 buffer holding the B waveforms back to back;
+ *            out_lens[b] = samples of utterance b (600 * predicted frames).  Free with
+ *            kx_free_audio.  The reference likewise returns an owned copy
+ *            (ort_koko.rs:85 `data.to_vec()`).
+ * Empty input (B = 0 or a len < 1) is an error, not a panic as in ort_koko.rs:56,61. */
+int kx_infer(kx_model* m, const int64_t* ids, int64_t t_stride, const int32_t* lens, int B,
+             const float* styles, const float* speeds, int n_speed, uint64_t seed,
+             uint32_t flags, float** out, int64_t* out_lens);
+
+void kx_free_audio(float* p);
+
+/* Device-resident form of the same call for batch serving and for bench.py: every
+ * pointer is GPU memory of this model's device, nothing crosses PCIe, nothing is
+ * allocated per call after the first call of a given shape.
+ *   d_audio      [B, audio_ld] float32, written for samples < 600*frames[b]
+ *   d_frames     [B] int32 predicted frame counts
+ * Returns KX_ERR_INVALID if audio_ld is smaller than the longest waveform (the needed
+ * length is then in *need_ld).  The call returns after the work has been queued on the
+ * model's stream and its frame counts are known; kx_sync waits for completion. */
+int kx_infer_device(kx_model* m, const int64_t* d_ids, int64_t t_stride, const int32_t* lens_host,
+                    int B, const float* d_styles, const float* speeds_host, int n_speed,
+                    uint64_t seed, uint32_t flags, float* d_audio, int64_t audio_ld,
+                    int32_t* d_frames, int64_t* need_ld);
+
+int kx_sync(kx_model* m);
+
+/* Benchmark control (SURVEY.md §8d "duration pinning"): when set, the predicted duration
+ * of token t is replaced by pattern[t % n] for every utterance (the duration head still
+ * runs).  n = 0 clears it. */
+int kx_set_pinned_durations(kx_model* m, const int32_t* pattern, int n);
+
+/* First utterance index used for the noise stream of the next calls (default 0). */
+int kx_set_utterance_base(kx_model* m, uint64_t utt_base);
+
+/* Per-kernel-class HIP-event timing on the model's stream (bench.py roofline leg).
+ * While enabled every launch of the conv1d MFMA kernel is bracketed by events.
+ * kx_profile_read drains them: launches, summed milliseconds and summed algorithmic
+ * FLOPs (2*Cout*Cin*k*columns per launch) since the last read. */
+int kx_profile_enable(kx_model* m, int on);
+int kx_profile_read(kx_model* m, int64_t* launches, double* total_ms, double* total_flops);
+
+/* ---- test hooks (used by tests/ only) --------------------------------------------- */
+
+/* Named intermediate of the last kx_infer*(…, KX_FLAG_TAPS): utterance b's [C, L] slab
+ * is copied to out (row-major, rows = channels).  Query with out = NULL to get C and L. */
+int kx_debug_tap(kx_model* m, const char* name, int b, float* out, int64_t out_cap,
+                 int32_t* C, int32_t* L);
+
+/* Stand-alone run of the conv1d MFMA kernel on host arrays (x [B,Cin,L], w [Cout,Cin,k]
+ * or, for transposed = 1, [Cin,Cout,k]); y must hold B*Cout*Lout floats.  act: 0 none,
+ * 1 leaky(slope), 2 snake(alpha[Cin]); norm = optional [3,B,Cin] (mean, scale, shift). */
+int kx_test_conv1d(int device_id, const float* x, int B, int Cin, int L, const float* w,
+                   const float* bias, int Cout, int k, int stride, int pad, int dil,
+                   int transposed, int act, float slope, const float* alpha,
+                   const float* norm, float* y, int Lout, char* err, size_t err_len);
+
+/* Stand-alone bidirectional LSTM (hidden 256): x [B,L,n_in] -> y [B,L,512]. */
+int kx_test_lstm(int device_id, const float* x, int B, int L, int n_in, const float* w_ih,
+                 const float* w_hh, const float* b_ih, const float* b_hh, const float* w_ih_r,
+                 const float* w_hh_r, const float* b_ih_r, const float* b_hh_r, float* y,
+                 char* err, size_t err_len);
+
+/* Stand-alone harmonic source: f0 [B, 2F] -> har_source [B, 600F] (bit-exact phase). */
+int kx_test_source(int device_id, const float* f0, int B, int F2, const float* lin_w,
+                   float lin_b, uint64_t seed, uint64_t utt_base, int noise_off, float* out,
+                   char* err, size_t err_len);
+
+const char* kx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KOKOROX_HIP_H */

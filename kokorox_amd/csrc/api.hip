@@ -1,0 +1,339 @@
+// extern "C" surface of libkokorox_hip.so (include/kokorox_hip.h).  Nothing throws across it.
+#include <cstring>
+#include <memory>
+
+#include "../../include/kokorox_hip.h"
+#include "model.h"
+
+using kx::Error;
+using kx::Model;
+
+struct kx_model {
+    std::unique_ptr<Model> m;
+};
+
+static void set_err(char* err, size_t n, const std::string& msg) {
+    if (err && n) {
+        strncpy(err, msg.c_str(), n - 1);
+        err[n - 1] = 0;
+    }
+}
+
+template <class F>
+static int guarded(kx_model* h, F&& f) {
+    if (!h || !h->m) return KX_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->m->mu);
+    try {
+        f(*h->m);
+        h->m->last_error.clear();
+        return KX_OK;
+    } catch (const Error& e) {
+        h->m->last_error = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        h->m->last_error = e.what();
+        return KX_ERR_DEVICE;
+    } catch (...) {
+        h->m->last_error = "unknown failure";
+        return KX_ERR_DEVICE;
+    }
+}
+
+template <class F>
+static int guarded_free(char* err, size_t n, F&& f) {
+    try {
+        f();
+        return KX_OK;
+    } catch (const Error& e) {
+        set_err(err, n, e.what());
+        return e.code;
+    } catch (const std::exception& e) {
+        set_err(err, n, e.what());
+        return KX_ERR_DEVICE;
+    } catch (...) {
+        set_err(err, n, "unknown failure");
+        return KX_ERR_DEVICE;
+    }
+}
+
+static void check_device(int device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) throw Error(KX_ERR_DEVICE, "no HIP device is visible (the HIP path has no CPU fallback)");
+    if (device_id < 0 || device_id >= n) throw Error(KX_ERR_INVALID, "device id out of range");
+    hipDeviceProp_t p;
+    KX_HIP(hipGetDeviceProperties(&p, device_id));
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
+        throw Error(KX_ERR_DEVICE, std::string("device is ") + p.gcnArchName + ", this library is built for gfx950 only");
+}
+
+namespace {
+struct DevMem {
+    std::vector<void*> p;
+    ~DevMem() {
+        for (void* q : p) (void)hipFree(q);
+    }
+    template <class Tp>
+    Tp* get(size_t n) {
+        void* q = nullptr;
+        KX_HIP(hipMalloc(&q, (n ? n : 1) * sizeof(Tp)));
+        p.push_back(q);
+        return static_cast<Tp*>(q);
+    }
+    template <class Tp>
+    Tp* up(const Tp* h, size_t n) {
+        Tp* d = get<Tp>(n);
+        KX_HIP(hipMemcpy(d, h, n * sizeof(Tp), hipMemcpyHostToDevice));
+        return d;
+    }
+};
+}  // namespace
+
+extern "C" {
+
+const char* kx_version(void) { return "kokorox-hip 0.1 (gfx950, f32 MFMA)"; }
+
+int kx_init(int device_id, char* err, size_t err_len) {
+    return guarded_free(err, err_len, [&] { check_device(device_id); });
+}
+
+kx_model* kx_create(const char* weights_path, int device_id, char* err, size_t err_len) {
+    kx_model* h = nullptr;
+    int rc = guarded_free(err, err_len, [&] {
+        check_device(device_id);
+        std::unique_ptr<Model> m(new Model(device_id));
+        m->load_file(weights_path);
+        h = new kx_model{std::move(m)};
+    });
+    return rc == KX_OK ? h : nullptr;
+}
+
+kx_model* kx_create_from_device_blob(const void* d_blob, size_t n_bytes, int device_id, char* err, size_t err_len) {
+    kx_model* h = nullptr;
+    int rc = guarded_free(err, err_len, [&] {
+        check_device(device_id);
+        std::unique_ptr<Model> m(new Model(device_id));
+        m->load_device_blob(d_blob, n_bytes);
+        h = new kx_model{std::move(m)};
+    });
+    return rc == KX_OK ? h : nullptr;
+}
+
+void kx_destroy(kx_model* m) {
+    if (!m) return;
+    try {
+        delete m;
+    } catch (...) {
+    }
+}
+
+const char* kx_last_error(const kx_model* m) { return (m && m->m) ? m->m->last_error.c_str() : "null model"; }
+
+int kx_infer(kx_model* m, const int64_t* ids, int64_t t_stride, const int32_t* lens, int B, const float* styles,
+             const float* speeds, int n_speed, uint64_t seed, uint32_t flags, float** out, int64_t* out_lens) {
+    return guarded(m, [&](Model& M) { M.infer_host(ids, t_stride, lens, B, styles, speeds, n_speed, seed, flags, out, out_lens); });
+}
+
+void kx_free_audio(float* p) { free(p); }
+
+int kx_infer_device(kx_model* m, const int64_t* d_ids, int64_t t_stride, const int32_t* lens_host, int B,
+                    const float* d_styles, const float* speeds_host, int n_speed, uint64_t seed, uint32_t flags,
+                    float* d_audio, int64_t audio_ld, int32_t* d_frames, int64_t* need_ld) {
+    return guarded(m, [&](Model& M) {
+        M.infer_device(d_ids, t_stride, lens_host, B, d_styles, speeds_host, n_speed, seed, flags, d_audio, audio_ld,
+                       d_frames, need_ld);
+    });
+}
+
+int kx_sync(kx_model* m) {
+    return guarded(m, [&](Model& M) { M.sync(); });
+}
+
+int kx_set_pinned_durations(kx_model* m, const int32_t* pattern, int n) {
+    return guarded(m, [&](Model& M) { M.set_pinned(pattern, n); });
+}
+
+int kx_set_utterance_base(kx_model* m, uint64_t utt_base) {
+    return guarded(m, [&](Model& M) { M.utt_base = utt_base; });
+}
+
+int kx_profile_enable(kx_model* m, int on) {
+    return guarded(m, [&](Model& M) { M.profile_enable(on != 0); });
+}
+
+int kx_profile_read(kx_model* m, int64_t* launches, double* total_ms, double* total_flops) {
+    return guarded(m, [&](Model& M) {
+        KX_REQUIRE(launches && total_ms && total_flops, "profile_read: null argument");
+        M.profile_read(launches, total_ms, total_flops);
+    });
+}
+
+int kx_debug_tap(kx_model* m, const char* name, int b, float* out, int64_t out_cap, int32_t* C, int32_t* L) {
+    return guarded(m, [&](Model& M) {
+        KX_REQUIRE(name && C && L, "debug_tap: null argument");
+        const kx::Tap* t = M.find_tap(name);
+        if (!t) throw Error(KX_ERR_STATE, std::string("no such tap (was KX_FLAG_TAPS set?): ") + name);
+        KX_REQUIRE(b >= 0 && b < t->B, "debug_tap: utterance index out of range");
+        *C = t->C;
+        *L = t->L[b];
+        if (!out) return;
+        KX_REQUIRE(out_cap >= (int64_t)t->C * t->L[b], "debug_tap: output buffer too small");
+        for (int c = 0; c < t->C; ++c)
+            memcpy(out + (size_t)c * t->L[b], t->data.data() + ((size_t)b * t->C + c) * t->ld, (size_t)t->L[b] * 4);
+    });
+}
+
+// ---- stand-alone kernel hooks for tests/ ------------------------------------------------------
+
+int kx_test_conv1d(int device_id, const float* x, int B, int Cin, int L, const float* w, const float* bias, int Cout,
+                   int k, int stride, int pad, int dil, int transposed, int act, float slope, const float* alpha,
+                   const float* norm, float* y, int Lout, char* err, size_t err_len) {
+    return guarded_free(err, err_len, [&] {
+        check_device(device_id);
+        KX_REQUIRE(x && w && y && B > 0 && Cin > 0 && Cout > 0 && L > 0 && Lout > 0 && k > 0, "test_conv1d: bad argument");
+        KX_HIP(hipSetDevice(device_id));
+        DevMem dm;
+        std::vector<int> lens(B, 1);
+        kx::ConvArgs a{};
+        a.x = dm.up(x, (size_t)B * Cin * L);
+        a.x_bs = (long)Cin * L;
+        a.x_ld = L;
+        a.Cin = Cin;
+        int* d_one = dm.up(lens.data(), B);
+        a.in_len = kx::LenMap{d_one, 0, L};
+        a.out_len = kx::LenMap{d_one, 0, Lout};
+        a.n_chunks = (Cin + kx::CONV_CK - 1) / kx::CONV_CK;
+        const float* dw = dm.up(w, (size_t)Cout * Cin * k);
+        int BM, rows;
+        float* packed;
+        if (!transposed) {
+            rows = Cout;
+            BM = kx::conv_pick_bm(rows);
+            packed = dm.get<float>(kx::packed_conv_floats(rows, Cin, k, BM));
+            kx::PackSrc src{{dw, nullptr, nullptr}, {Cout, 0, 0}};
+            kx::launch_pack_conv(src, packed, Cout, Cin, k, BM, nullptr);
+            a.K = k;
+            a.stride = stride;
+            a.pad = pad;
+            a.dil = dil;
+            a.store = kx::ST_NORMAL;
+            a.up_cout = 1;
+        } else {
+            KX_REQUIRE(k == 2 * stride && pad == (k - stride) / 2 && dil == 1, "test_conv1d: transposed needs k=2s, pad=(k-s)/2");
+            rows = stride * Cout;
+            BM = kx::conv_pick_bm(rows);
+            packed = dm.get<float>(kx::packed_conv_floats(rows, Cin, 2, BM));
+            kx::launch_pack_convT(dw, packed, Cin, Cout, stride, BM, nullptr);
+            a.K = 2;
+            a.stride = 1;
+            a.pad = 1;
+            a.dil = 1;
+            a.store = kx::ST_UPSCATTER;
+            a.up_s = stride;
+            a.up_pad = pad;
+            a.up_cout = Cout;
+        }
+        a.Cout = rows;
+        a.w = packed;
+        a.bias = bias ? dm.up(bias, (size_t)Cout) : nullptr;
+        if (norm) {
+            const float* dn = dm.up(norm, (size_t)3 * B * Cin);
+            a.nmean = dn;
+            a.nscale = dn + (size_t)B * Cin;
+            a.nshift = dn + (size_t)2 * B * Cin;
+            a.n_bs = Cin;
+        }
+        a.act = act;
+        a.slope = slope;
+        a.alpha = alpha ? dm.up(alpha, (size_t)Cin) : nullptr;
+        KX_REQUIRE(act != kx::ACT_SNAKE || alpha, "test_conv1d: snake needs alpha");
+        float* dy = dm.get<float>((size_t)B * Cout * Lout);
+        KX_HIP(hipMemset(dy, 0, (size_t)B * Cout * Lout * 4));
+        a.y = dy;
+        a.y_bs = (long)Cout * Lout;
+        a.y_ld = Lout;
+        a.out_mul = 1.f;
+        a.out_div = 1.f;
+        kx::launch_conv1d(a, BM, B, transposed ? L + 1 : Lout, nullptr);
+        KX_HIP(hipDeviceSynchronize());
+        KX_HIP(hipMemcpy(y, dy, (size_t)B * Cout * Lout * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+int kx_test_lstm(int device_id, const float* x, int B, int L, int n_in, const float* w_ih, const float* w_hh,
+                 const float* b_ih, const float* b_hh, const float* w_ih_r, const float* w_hh_r, const float* b_ih_r,
+                 const float* b_hh_r, float* y, char* err, size_t err_len) {
+    return guarded_free(err, err_len, [&] {
+        check_device(device_id);
+        KX_REQUIRE(x && y && B > 0 && L > 0 && n_in > 0, "test_lstm: bad argument");
+        KX_HIP(hipSetDevice(device_id));
+        DevMem dm;
+        std::vector<float> xc((size_t)B * n_in * L);  // [B,L,n_in] -> channel-major [B][n_in][L]
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < L; ++t)
+                for (int c = 0; c < n_in; ++c) xc[((size_t)b * n_in + c) * L + t] = x[((size_t)b * L + t) * n_in + c];
+        std::vector<int> lens(B, L);
+        int* d_len = dm.up(lens.data(), B);
+        kx::ConvArgs a{};
+        a.x = dm.up(xc.data(), xc.size());
+        a.x_bs = (long)n_in * L;
+        a.x_ld = L;
+        a.Cin = n_in;
+        a.in_len = kx::LenMap{d_len, 1, 0};
+        a.out_len = a.in_len;
+        a.n_chunks = (n_in + kx::CONV_CK - 1) / kx::CONV_CK;
+        float* packed = dm.get<float>(kx::packed_conv_floats(2048, n_in, 1, 128));
+        kx::PackSrc src{{dm.up(w_ih, (size_t)1024 * n_in), dm.up(w_ih_r, (size_t)1024 * n_in), nullptr}, {1024, 1024, 0}};
+        kx::launch_pack_conv(src, packed, 2048, n_in, 1, 128, nullptr);
+        float* bias = dm.get<float>(2048);
+        kx::launch_vec_add(dm.up(b_ih, 1024), dm.up(b_hh, 1024), bias, 1024, nullptr);
+        kx::launch_vec_add(dm.up(b_ih_r, 1024), dm.up(b_hh_r, 1024), bias + 1024, 1024, nullptr);
+        float* whhT = dm.get<float>(2 * 256 * 1024);
+        kx::launch_transpose_whh(dm.up(w_hh, 1024 * 256), whhT, nullptr);
+        kx::launch_transpose_whh(dm.up(w_hh_r, 1024 * 256), whhT + 256 * 1024, nullptr);
+        float* gx = dm.get<float>((size_t)B * L * 2048);
+        a.w = packed;
+        a.bias = bias;
+        a.K = 1; a.dil = 1; a.stride = 1; a.pad = 0;
+        a.Cout = 2048;
+        a.y = gx;
+        a.y_bs = (long)L * 2048;
+        a.y_ld = 2048;
+        a.out_mul = 1.f; a.out_div = 1.f;
+        a.store = kx::ST_TMAJOR;
+        a.up_cout = 1;
+        kx::launch_conv1d(a, 128, B, L, nullptr);
+        float* dy = dm.get<float>((size_t)B * 512 * L);
+        kx::launch_lstm(gx, (long)L * 2048, 2048, whhT, dy, (long)512 * L, L, kx::LenMap{d_len, 1, 0}, B, nullptr);
+        KX_HIP(hipDeviceSynchronize());
+        std::vector<float> yc((size_t)B * 512 * L);
+        KX_HIP(hipMemcpy(yc.data(), dy, yc.size() * 4, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < 512; ++c)
+                for (int t = 0; t < L; ++t) y[((size_t)b * L + t) * 512 + c] = yc[((size_t)b * 512 + c) * L + t];
+    });
+}
+
+int kx_test_source(int device_id, const float* f0, int B, int F2, const float* lin_w, float lin_b, uint64_t seed,
+                   uint64_t utt_base, int noise_off, float* out, char* err, size_t err_len) {
+    return guarded_free(err, err_len, [&] {
+        check_device(device_id);
+        KX_REQUIRE(f0 && lin_w && out && B > 0 && F2 > 0 && (F2 % 2) == 0, "test_source: bad argument");
+        KX_HIP(hipSetDevice(device_id));
+        kx::init_dft_tables();
+        DevMem dm;
+        const int F = F2 / 2;
+        std::vector<int> fr(B, F);
+        int* d_fr = dm.up(fr.data(), B);
+        const float* d_f0 = dm.up(f0, (size_t)B * F2);
+        const float* d_w = dm.up(lin_w, 9);
+        const float* d_b = dm.up(&lin_b, 1);
+        float* phase = dm.get<float>((size_t)B * 9 * F2);
+        float* har = dm.get<float>((size_t)B * 600 * F);
+        kx::launch_source(d_f0, F2, d_fr, B, F, d_w, d_b, seed, utt_base, noise_off, phase, har, (long)600 * F, nullptr);
+        KX_HIP(hipDeviceSynchronize());
+        KX_HIP(hipMemcpy(out, har, (size_t)B * 600 * F * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,613 @@
+// Non-contraction kernels of the Kokoro-82M forward (gfx950): gathers, channel layer-norm,
+// instance-norm statistics, small-T attention, LSTM recurrence, duration/alignment,
+// harmonic source (SineGen), forward STFT and the inverse-STFT head.  All activations are
+// channel-major [B][C][ld] with per-utterance valid lengths (ragged batch, no cross-
+// utterance reads).  These are the HBM-/latency-bound passes of SURVEY.md A.4; the dense
+// work is in conv_mfma.hip.
+#include <cmath>
+
+#include "kx_common.h"
+
+namespace kx {
+
+__device__ __forceinline__ int len_of(const LenMap& m, int b) { return m.lens[b] * m.mul + m.add; }
+
+// ---------------------------------------------------------------------------------------
+__global__ void vec_add_kernel(const float* a, const float* b, float* out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + (b ? b[i] : 0.f);
+}
+void launch_vec_add(const float* a, const float* b, float* out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(vec_add_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, out, n);
+    KX_HIP(hipGetLastError());
+}
+
+__global__ void transpose_whh_kernel(const float* w, float* out) {  // [1024][256] -> [256][1024]
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 1024 * 256) {
+        int r = i / 256, k = i % 256;
+        out[k * 1024 + r] = w[i];
+    }
+}
+void launch_transpose_whh(const float* whh, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_whh_kernel, dim3(1024), dim3(256), 0, s, whh, out);
+    KX_HIP(hipGetLastError());
+}
+
+// ---- embeddings -------------------------------------------------------------------------
+// ALBERT: word[id] + token_type[0] + position[t]  (channel-major out [B][128][ld])
+__global__ void albert_embed_kernel(const int64_t* ids, long ids_stride, const float* word, const float* type0,
+                                    const float* pos, float* out, long bs, int ld, const int* lens) {
+    const int t = blockIdx.x, b = blockIdx.y, e = threadIdx.x;
+    if (t >= lens[b]) return;
+    const long id = ids[b * ids_stride + t];
+    out[b * bs + (long)e * ld + t] = (word[id * 128 + e] + type0[e]) + pos[t * 128 + e];
+}
+void launch_albert_embed(const int64_t* ids, long ids_stride, const float* word, const float* type0,
+                         const float* pos, float* out, long bs, int ld, const int* lens, int B, int Tmax,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(albert_embed_kernel, dim3(Tmax, B), dim3(128), 0, s, ids, ids_stride, word, type0, pos,
+                       out, bs, ld, lens);
+    KX_HIP(hipGetLastError());
+}
+
+__global__ void embed_kernel(const int64_t* ids, long ids_stride, const float* table, int C, float* out, long bs,
+                             int ld, const int* lens) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    if (t >= lens[b]) return;
+    const long id = ids[b * ids_stride + t];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) out[b * bs + (long)c * ld + t] = table[id * C + c];
+}
+void launch_embed(const int64_t* ids, long ids_stride, const float* table, int C, float* out, long bs, int ld,
+                  const int* lens, int B, int Tmax, hipStream_t s) {
+    hipLaunchKernelGGL(embed_kernel, dim3(Tmax, B), dim3(256), 0, s, ids, ids_stride, table, C, out, bs, ld, lens);
+    KX_HIP(hipGetLastError());
+}
+
+// ---- channel layer-norm -------------------------------------------------------------------
+// 64 time columns x 4 channel groups per workgroup; reads are coalesced along time.
+__global__ __launch_bounds__(256) void layernorm_ch_kernel(const float* x, float* y, long bs, int ld, int C,
+                                                           LenMap len, float eps, int mode, const float* g,
+                                                           const float* be, int g_bs, float leaky) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int b = blockIdx.y, t = blockIdx.x * 64 + tx;
+    const int L = len_of(len, b);
+    const bool ok = t < L;
+    const float* xb = x + b * bs + t;
+    float s = 0.f;
+    if (ok)
+        for (int c = cg; c < C; c += 4) s += xb[(long)c * ld];
+    red[cg][tx] = s;
+    __syncthreads();
+    const float mean = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) / (float)C;
+    __syncthreads();
+    float v = 0.f;
+    if (ok)
+        for (int c = cg; c < C; c += 4) {
+            float d = xb[(long)c * ld] - mean;
+            v += d * d;
+        }
+    red[cg][tx] = v;
+    __syncthreads();
+    const float var = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) / (float)C;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (!ok) return;
+    float* yb = y + b * bs + t;
+    for (int c = cg; c < C; c += 4) {
+        float o = (xb[(long)c * ld] - mean) * rstd;
+        if (mode == LN_AFFINE)
+            o = o * g[c] + be[c];
+        else if (mode == LN_ADA)
+            o = (1.0f + g[(long)b * g_bs + c]) * o + be[(long)b * g_bs + c];
+        if (leaky != 0.f) o = o > 0.f ? o : o * leaky;
+        yb[(long)c * ld] = o;
+    }
+}
+void launch_layernorm_ch(const float* x, float* y, long bs, int ld, int C, LenMap len, int B, int Lmax, float eps,
+                         int mode, const float* g, const float* be, int g_bs, float leaky, hipStream_t s) {
+    if (Lmax <= 0) return;
+    hipLaunchKernelGGL(layernorm_ch_kernel, dim3((Lmax + 63) / 64, B), dim3(256), 0, s, x, y, bs, ld, C, len, eps,
+                       mode, g, be, g_bs, leaky);
+    KX_HIP(hipGetLastError());
+}
+
+// ---- ALBERT self-attention, 12 heads x 64, T <= 512 ---------------------------------------
+// qkv [B][2304][ld] = rows [Q | K | V]; one workgroup per (utterance, head), one wave per
+// query row: lanes span keys for QK^T + softmax (wave shuffles), then span the 64 head
+// dims for P.V.  ~0.1 % of the model's FLOPs.
+__global__ __launch_bounds__(256) void attention_kernel(const float* qkv, long bs, int ld, float* ctx, long cbs,
+                                                        int cld, const int* lens) {
+    __shared__ float ps[4][512];
+    __shared__ float qs[4][64];
+    const int b = blockIdx.x, hd = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int T = lens[b];
+    const float* Q = qkv + b * bs + (long)(hd * 64) * ld;
+    const float* Kp = Q + (long)768 * ld;
+    const float* V = Q + (long)1536 * ld;
+    const int nslot = (T + 63) >> 6;
+    for (int i = wave; i < T; i += 4) {
+        qs[wave][lane] = Q[(long)lane * ld + i];
+        __builtin_amdgcn_wave_barrier();
+        float sc[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) sc[m] = 0.f;
+        for (int d = 0; d < 64; ++d) {
+            const float qd = qs[wave][d];
+            const float* kr = Kp + (long)d * ld;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int j = lane + 64 * m;
+                if (m < nslot && j < T) sc[m] += qd * kr[j];
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int j = lane + 64 * m;
+            sc[m] = (m < nslot && j < T) ? sc[m] * 0.125f : -INFINITY;
+            mx = fmaxf(mx, sc[m]);
+        }
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int j = lane + 64 * m;
+            if (m < nslot && j < T) {
+                sc[m] = expf(sc[m] - mx);
+                sum += sc[m];
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int j = lane + 64 * m;
+            if (m < nslot && j < T) ps[wave][j] = sc[m] / sum;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float* vr = V + (long)lane * ld;
+        float o = 0.f;
+        for (int j = 0; j < T; ++j) o += ps[wave][j] * vr[j];
+        ctx[b * cbs + (long)(hd * 64 + lane) * cld + i] = o;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+void launch_attention(const float* qkv, long bs, int ld, float* ctx, long cbs, int cld, const int* lens, int B,
+                      int Tmax, hipStream_t s) {
+    KX_REQUIRE(Tmax <= 512, "attention: T > 512");
+    hipLaunchKernelGGL(attention_kernel, dim3(B, 12), dim3(256), 0, s, qkv, bs, ld, ctx, cbs, cld, lens);
+    KX_HIP(hipGetLastError());
+}
+
+// ---- all AdaIN / AdaLayerNorm style projections of one call ------------------------------
+__global__ __launch_bounds__(256) void style_fc_kernel(const FcDesc* desc, const float* styles, float* out,
+                                                       long out_bs) {
+    __shared__ float sv[128];
+    const FcDesc d = desc[blockIdx.x];
+    const int b = blockIdx.y;
+    if (threadIdx.x < 128) sv[threadIdx.x] = styles[b * 256 + d.style_off + threadIdx.x];
+    __syncthreads();
+    for (int o = threadIdx.x; o < d.n_out; o += 256) {
+        const float4* wr = reinterpret_cast<const float4*>(d.w + (long)o * 128);
+        float acc = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const float4 w4 = wr[k];
+            acc += w4.x * sv[4 * k] + w4.y * sv[4 * k + 1] + w4.z * sv[4 * k + 2] + w4.w * sv[4 * k + 3];
+        }
+        out[b * out_bs + d.out_off + o] = acc + d.b[o];
+    }
+}
+void launch_style_fc(const FcDesc* d_desc, int n_desc, const float* styles, float* out, long out_bs, int B,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(style_fc_kernel, dim3(n_desc, B), dim3(256), 0, s, d_desc, styles, out, out_bs);
+    KX_HIP(hipGetLastError());
+}
+
+// ---- instance-norm statistics (f64 accumulation) ------------------------------------------
+__global__ __launch_bounds__(256) void in_stats_kernel(const float* x, long bs, int ld, LenMap len, const float* gb,
+                                                       long gb_bs, int C, float* mean, float* scale, float* shift,
+                                                       int n_bs) {
+    __shared__ double rs[4], rq[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int L = len_of(len, b);
+    const float* row = x + b * bs + (long)c * ld;
+    double s = 0.0, q = 0.0;
+    for (int t = threadIdx.x; t < L; t += 256) {
+        const double v = (double)row[t];
+        s += v;
+        q += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o);
+        q += __shfl_down(q, o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        rs[wave] = s;
+        rq[wave] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double S = (rs[0] + rs[1]) + (rs[2] + rs[3]), Q = (rq[0] + rq[1]) + (rq[2] + rq[3]);
+        const double m = L > 0 ? S / L : 0.0;
+        double var = L > 0 ? Q / L - m * m : 0.0;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+        const float g = gb[b * gb_bs + c], be = gb[b * gb_bs + C + c];
+        mean[(long)b * n_bs + c] = (float)m;
+        scale[(long)b * n_bs + c] = (1.0f + g) * rstd;
+        shift[(long)b * n_bs + c] = be;
+    }
+}
+void launch_in_stats(const float* x, long bs, int ld, int C, LenMap len, int B, const float* gb, long gb_bs,
+                     float* mean, float* scale, float* shift, int n_bs, hipStream_t s) {
+    hipLaunchKernelGGL(in_stats_kernel, dim3(C, B), dim3(256), 0, s, x, bs, ld, len, gb, gb_bs, C, mean, scale,
+                       shift, n_bs);
+    KX_HIP(hipGetLastError());
+}
+
+// ---- row fills / copies ---------------------------------------------------------------------
+__global__ void fill_style_rows_kernel(float* dst, long bs, int ld, int row0, const float* styles, int style_off,
+                                       const int* lens) {
+    const int k = blockIdx.x, b = blockIdx.y;
+    const float v = styles[b * 256 + style_off + k];
+    const int L = lens[b];
+    float* row = dst + b * bs + (long)(row0 + k) * ld;
+    for (int t = threadIdx.x; t < L; t += blockDim.x) row[t] = v;
+}
+void launch_fill_style_rows(float* dst, long bs, int ld, int row0, const float* styles, int style_off,
+                            const int* lens, int B, int Tmax, hipStream_t s) {
+    (void)Tmax;
+    hipLaunchKernelGGL(fill_style_rows_kernel, dim3(128, B), dim3(256), 0, s, dst, bs, ld, row0, styles, style_off,
+                       lens);
+    KX_HIP(hipGetLastError());
+}
+
+__global__ void copy_rows_kernel(const float* src, long sbs, int sld, float* dst, long dbs, int dld, LenMap len) {
+    const int r = blockIdx.x, b = blockIdx.y;
+    const int L = len_of(len, b);
+    const float* s = src + b * sbs + (long)r * sld;
+    float* d = dst + b * dbs + (long)r * dld;
+    for (int t = threadIdx.x; t < L; t += blockDim.x) d[t] = s[t];
+}
+void launch_copy_rows(const float* src, long sbs, int sld, float* dst, long dbs, int dld, int rows, LenMap len,
+                      int B, int Lmax, hipStream_t s) {
+    (void)Lmax;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(rows, B), dim3(256), 0, s, src, sbs, sld, dst, dbs, dld, len);
+    KX_HIP(hipGetLastError());
+}
+
+// ---- bidirectional LSTM recurrence (hidden 256) -------------------------------------------
+// gx [B][L][2048] holds W_ih x + b_ih + b_hh for both directions (conv_mfma, time-major
+// store).  One workgroup of 1024 threads per (utterance, direction): thread r owns gate
+// row r, streams W_hh^T[k][r] (coalesced, L2-resident: 1 MB per direction) against h in
+// LDS, then the first 256 threads apply the cell update.
+__global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gx_bs, int gx_ld, const float* whhT,
+                                                    float* y, long y_bs, int y_ld, LenMap len) {
+    __shared__ __attribute__((aligned(16))) float hs[256];
+    __shared__ float gates[1024];
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    const int L = len_of(len, b);
+    const float* W = whhT + (long)dir * 256 * 1024 + tid;
+    float c = 0.f;
+    if (tid < 256) hs[tid] = 0.f;
+    __syncthreads();
+    for (int step = 0; step < L; ++step) {
+        const int t = dir ? (L - 1 - step) : step;
+        float acc = gx[b * gx_bs + (long)t * gx_ld + dir * 1024 + tid];
+        const float4* h4 = reinterpret_cast<const float4*>(hs);
+#pragma unroll 4
+        for (int k4 = 0; k4 < 64; ++k4) {
+            const float4 hv = h4[k4];
+            const float* w = W + (long)k4 * 4 * 1024;
+            acc = fmaf(w[0], hv.x, acc);
+            acc = fmaf(w[1024], hv.y, acc);
+            acc = fmaf(w[2048], hv.z, acc);
+            acc = fmaf(w[3072], hv.w, acc);
+        }
+        gates[tid] = acc;
+        __syncthreads();
+        if (tid < 256) {
+            const float ig = 1.0f / (1.0f + expf(-gates[tid]));
+            const float fg = 1.0f / (1.0f + expf(-gates[256 + tid]));
+            const float gg = tanhf(gates[512 + tid]);
+            const float og = 1.0f / (1.0f + expf(-gates[768 + tid]));
+            c = fg * c + ig * gg;
+            const float hn = og * tanhf(c);
+            hs[tid] = hn;
+            y[b * y_bs + (long)(dir * 256 + tid) * y_ld + t] = hn;
+        }
+        __syncthreads();
+    }
+}
+void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, float* y, long y_bs, int y_ld,
+                 LenMap len, int B, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_kernel, dim3(B, 2), dim3(1024), 0, s, gx, gx_bs, gx_ld, whhT, y, y_bs, y_ld, len);
+    KX_HIP(hipGetLastError());
+}
+
+// ---- duration head + alignment ---------------------------------------------------------------
+// dur[t] = clamp(round(sum_c sigmoid(logit[c][t]) / speed), min 1); frames = sum; idx = the
+// repeat_interleave gather index (model.py forward_with_tokens).
+__global__ __launch_bounds__(512) void duration_kernel(const float* logits, long bs, int ld, const float* speeds,
+                                                       int n_speed, const int* lens, const int* pinned,
+                                                       int n_pinned, int* dur, int* frames, int* idx, int idx_ld) {
+    __shared__ int scan[512];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int T = lens[b];
+    int d = 0;
+    if (t < T) {
+        float s = 0.f;
+        for (int c = 0; c < 50; ++c) s += 1.0f / (1.0f + expf(-logits[b * bs + (long)c * ld + t]));
+        s = s / speeds[n_speed > 1 ? b : 0];
+        s = rintf(s);
+        d = s < 1.f ? 1 : (int)s;
+        if (n_pinned > 0) d = pinned[t % n_pinned];
+        dur[b * 512 + t] = d;
+    }
+    scan[t] = d;
+    __syncthreads();
+    for (int o = 1; o < 512; o <<= 1) {
+        const int v = (t >= o) ? scan[t - o] : 0;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    if (t == 511) frames[b] = scan[511];
+    if (t < T) {
+        const int start = scan[t] - d;
+        for (int f = 0; f < d; ++f) idx[(long)b * idx_ld + start + f] = t;
+    }
+}
+void launch_duration(const float* logits, long bs, int ld, const float* speeds, int n_speed, const int* lens,
+                     const int* pinned, int n_pinned, int* dur, int* frames, int* idx, int idx_ld, int B,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(duration_kernel, dim3(B), dim3(512), 0, s, logits, bs, ld, speeds, n_speed, lens, pinned,
+                       n_pinned, dur, frames, idx, idx_ld);
+    KX_HIP(hipGetLastError());
+}
+
+__global__ void gather_cols_kernel(const float* src, long sbs, int sld, float* dst, long dbs, int dld,
+                                   const int* idx, int idx_ld, const int* frames) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (f >= frames[b]) return;
+    dst[b * dbs + (long)c * dld + f] = src[b * sbs + (long)c * sld + idx[(long)b * idx_ld + f]];
+}
+void launch_gather_cols(const float* src, long sbs, int sld, float* dst, long dbs, int dld, int C, const int* idx,
+                        int idx_ld, const int* frames, int B, int Fmax, hipStream_t s) {
+    hipLaunchKernelGGL(gather_cols_kernel, dim3((Fmax + 255) / 256, C, B), dim3(256), 0, s, src, sbs, sld, dst, dbs,
+                       dld, idx, idx_ld, frames);
+    KX_HIP(hipGetLastError());
+}
+
+// ---- AdainResBlk1d up-sampling "pool" ---------------------------------------------------------
+// depth-wise ConvTranspose1d(k3, s2, p1, output_padding 1) over v = leaky(adain(x)):
+//   out[2m] = v[m] w1 + b ;  out[2m+1] = v[m] w2 + v[m+1] w0 + b
+__global__ void pool_up2_kernel(const float* x, long xbs, int xld, const float* mean, const float* scale,
+                                const float* shift, int n_bs, float slope, const float* w, const float* bias,
+                                float* y, long ybs, int yld, LenMap in_len) {
+    const int t2 = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    const int L = len_of(in_len, b);
+    if (t2 >= 2 * L) return;
+    const float mu = mean[(long)b * n_bs + c], sc = scale[(long)b * n_bs + c], sh = shift[(long)b * n_bs + c];
+    const float* row = x + b * xbs + (long)c * xld;
+    const int m = t2 >> 1;
+    float v0 = (row[m] - mu) * sc + sh;
+    v0 = v0 > 0.f ? v0 : v0 * slope;
+    float o;
+    if ((t2 & 1) == 0) {
+        o = v0 * w[c * 3 + 1];
+    } else {
+        float v1 = 0.f;
+        if (m + 1 < L) {
+            v1 = (row[m + 1] - mu) * sc + sh;
+            v1 = v1 > 0.f ? v1 : v1 * slope;
+        }
+        o = v0 * w[c * 3 + 2] + v1 * w[c * 3 + 0];
+    }
+    y[b * ybs + (long)c * yld + t2] = o + bias[c];
+}
+void launch_pool_up2(const float* x, long xbs, int xld, int C, const float* mean, const float* scale,
+                     const float* shift, int n_bs, float slope, const float* w, const float* bias, float* y,
+                     long ybs, int yld, LenMap in_len, int B, int Lmax_in, hipStream_t s) {
+    hipLaunchKernelGGL(pool_up2_kernel, dim3((2 * Lmax_in + 255) / 256, C, B), dim3(256), 0, s, x, xbs, xld, mean,
+                       scale, shift, n_bs, slope, w, bias, y, ybs, yld, in_len);
+    KX_HIP(hipGetLastError());
+}
+
+// ---- harmonic source (SourceModuleHnNSF / SineGen, istftnet.py) ---------------------------
+// The phase path is bit-exact with torch CPU float32: rad = (f0*h/24000) mod 1, cumulative
+// sum accumulated in float64 and rounded per step (torch.cumsum on CPU), x 2 x pi x 300, then
+// the x300 linear up-sampling  src = fma(1/300, j+0.5, -0.5);  out = fma(l0, p0, l1*p1).
+// Phases reach ~1e5 rad, where one float32 ulp is ~0.008 rad, so any other operation order
+// decorrelates the harmonics ("Parity").
+__global__ void source_phase_kernel(const float* f0, long f0_bs, const int* frames, float* phase, int L2max) {
+    const int b = blockIdx.x, h = threadIdx.x;
+    if (h >= 9) return;
+    const int n2 = 2 * frames[b];
+    const float hm = (float)(h + 1);
+    double cs = 0.0;
+    float* out = phase + ((long)b * 9 + h) * L2max;
+    for (int i = 0; i < n2; ++i) {
+        const float fn = __fmul_rn(f0[b * f0_bs + i], hm);
+        float rad = fmodf(__fdiv_rn(fn, 24000.0f), 1.0f);
+        if (rad < 0.f) rad = __fadd_rn(rad, 1.0f);
+        cs += (double)rad;
+        const float c32 = (float)cs;
+        out[i] = __fmul_rn(__fmul_rn(__fmul_rn(c32, 2.0f), 3.14159274101257324f), 300.0f);
+    }
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t& o0, uint32_t& o1) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    o0 = c0;
+    o1 = c1;
+}
+
+__global__ void source_sample_kernel(const float* f0, long f0_bs, const int* frames, const float* phase, int L2max,
+                                     const float* lin_w, const float* lin_b, uint32_t k0, uint32_t k1,
+                                     uint64_t utt_base, int noise_off, float* har, long har_bs) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    const int n2 = 2 * frames[b];
+    if (j >= 300 * n2) return;
+    const float f0v = f0[b * f0_bs + j / 300];
+    const bool uv = f0v > 10.0f;
+    const float scale = (float)(1.0 / 300.0);
+    float src = fmaf(scale, (float)j + 0.5f, -0.5f);
+    if (src < 0.f) src = 0.f;
+    const int i0 = (int)src;
+    const float l1 = __fsub_rn(src, (float)i0), l0 = __fsub_rn(1.0f, l1);
+    const int i1 = i0 + (i0 < n2 - 1 ? 1 : 0);
+    const float amp = uv ? 0.003f : (0.1f / 3.0f);
+    const uint32_t utt = (uint32_t)(utt_base + (uint64_t)b);
+    float acc = 0.f;
+#pragma unroll
+    for (int h = 0; h < 9; ++h) {
+        const float* P = phase + ((long)b * 9 + h) * L2max;
+        const float ph = fmaf(l0, P[i0], __fmul_rn(l1, P[i1]));
+        const float sv = sinf(ph) * 0.1f;
+        float nz = 0.f;
+        if (!noise_off) {
+            uint32_t x0, x1;
+            philox4x32_10((uint32_t)j, (uint32_t)h, utt, 0u, k0, k1, x0, x1);
+            const float u1 = ((float)(x0 >> 9) + 0.5f) * 1.1920928955078125e-07f;
+            const float u2 = ((float)(x1 >> 9) + 0.5f) * 1.1920928955078125e-07f;
+            const float rr = sqrtf(-2.0f * logf(u1));
+            nz = amp * (rr * cosf(6.2831855f * u2));
+        }
+        const float sw = uv ? (sv + nz) : nz;
+        acc += lin_w[h] * sw;
+    }
+    har[b * har_bs + j] = tanhf(acc + lin_b[0]);
+}
+
+void launch_source(const float* f0, long f0_bs, const int* frames, int B, int Fmax, const float* lin_w,
+                   const float* lin_b, uint64_t seed, uint64_t utt_base, int noise_off, float* phase_ws, float* har,
+                   long har_bs, hipStream_t s) {
+    const int L2max = 2 * Fmax;
+    hipLaunchKernelGGL(source_phase_kernel, dim3(B), dim3(64), 0, s, f0, f0_bs, frames, phase_ws, L2max);
+    KX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(source_sample_kernel, dim3((600 * Fmax + 255) / 256, B), dim3(256), 0, s, f0, f0_bs, frames,
+                       phase_ws, L2max, lin_w, lin_b, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32),
+                       utt_base, noise_off, har, har_bs);
+    KX_HIP(hipGetLastError());
+}
+
+// ---- STFT (n_fft 20, hop 5, periodic Hann, replicate centre padding) and iSTFT head -------
+__constant__ float c_fwd_re[11][20];
+__constant__ float c_fwd_im[11][20];
+__constant__ float c_inv_re[20][11];
+__constant__ float c_inv_im[20][11];
+__constant__ float c_win_sq[20];
+
+void init_dft_tables() {
+    double c[20], sn[20], win[20];
+    for (int m = 0; m < 20; ++m) {
+        c[m] = cos(2.0 * M_PI * m / 20.0);
+        sn[m] = sin(2.0 * M_PI * m / 20.0);
+        win[m] = 0.5 - 0.5 * cos(2.0 * M_PI * m / 20.0);
+    }
+    c[0] = 1; c[5] = 0; c[10] = -1; c[15] = 0;
+    sn[0] = 0; sn[5] = 1; sn[10] = 0; sn[15] = -1;
+    float fr[11][20], fi[11][20], ir[20][11], ii[20][11], wsq[20];
+    for (int k = 0; k < 11; ++k)
+        for (int n = 0; n < 20; ++n) {
+            const int m = (k * n) % 20;
+            fr[k][n] = (float)(win[n] * c[m]);
+            fi[k][n] = (float)(win[n] * (-sn[m]));
+            const double ck = (k == 0 || k == 10) ? 1.0 : 2.0;
+            ir[n][k] = (float)((ck * c[m]) / 20.0 * win[n]);
+            ii[n][k] = (k == 0 || k == 10) ? 0.f : (float)((-ck * sn[m]) / 20.0 * win[n]);
+        }
+    for (int n = 0; n < 20; ++n) wsq[n] = (float)(win[n] * win[n]);
+    KX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_fwd_re), fr, sizeof(fr)));
+    KX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_fwd_im), fi, sizeof(fi)));
+    KX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_inv_re), ir, sizeof(ir)));
+    KX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_inv_im), ii, sizeof(ii)));
+    KX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_win_sq), wsq, sizeof(wsq)));
+}
+
+__global__ void stft_kernel(const float* hs, long hs_bs, float* har, long bs, int ld, const int* frames) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    const int L = 600 * frames[b], nf = 120 * frames[b] + 1;
+    if (f >= nf) return;
+    float x[20];
+#pragma unroll
+    for (int n = 0; n < 20; ++n) {
+        int p = 5 * f - 10 + n;
+        p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
+        x[n] = hs[b * hs_bs + p];
+    }
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        float re = 0.f, im = 0.f;
+#pragma unroll
+        for (int n = 0; n < 20; ++n) {
+            re += x[n] * c_fwd_re[k][n];
+            im += x[n] * c_fwd_im[k][n];
+        }
+        har[b * bs + (long)k * ld + f] = sqrtf(re * re + im * im);
+        har[b * bs + (long)(11 + k) * ld + f] = atan2f(im, re);
+    }
+}
+void launch_stft(const float* har_src, long hs_bs, float* har, long bs, int ld, const int* frames, int B, int Fmax,
+                 hipStream_t s) {
+    hipLaunchKernelGGL(stft_kernel, dim3((120 * Fmax + 1 + 255) / 256, B), dim3(256), 0, s, har_src, hs_bs, har, bs,
+                       ld, frames);
+    KX_HIP(hipGetLastError());
+}
+
+// head: mag = exp(x[:11]), phase = sin(x[11:]) (Generator.forward), then torch.istft semantics
+__global__ void istft_spec_kernel(const float* cp, long bs, int ld, float* spec, const int* frames) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y, b = blockIdx.z;
+    const int nf = 120 * frames[b] + 1;
+    if (f >= nf) return;
+    const float mag = expf(cp[b * bs + (long)k * ld + f]);
+    const float ph = sinf(cp[b * bs + (long)(11 + k) * ld + f]);
+    spec[b * bs + (long)k * ld + f] = mag * cosf(ph);
+    spec[b * bs + (long)(11 + k) * ld + f] = mag * sinf(ph);
+}
+__global__ void istft_ola_kernel(const float* spec, long bs, int ld, float* audio, long audio_ld, const int* frames) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    const int nf = 120 * frames[b] + 1;
+    if (j >= 600 * frames[b]) return;
+    const int n = j + 10;
+    int fhi = n / 5;
+    if (fhi > nf - 1) fhi = nf - 1;
+    const int flo = n >= 19 ? (n - 15) / 5 : 0;
+    float y = 0.f, env = 0.f;
+    const float* sp = spec + b * bs;
+    for (int f = fhi; f >= flo; --f) {
+        const int m = n - 5 * f;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k)
+            acc += c_inv_re[m][k] * sp[(long)k * ld + f] + c_inv_im[m][k] * sp[(long)(11 + k) * ld + f];
+        y += acc;
+        env += c_win_sq[m];
+    }
+    audio[b * audio_ld + j] = y / env;
+}
+void launch_istft_head(const float* cp, long bs, int ld, float* spec_ws, float* audio, long audio_ld,
+                       const int* frames, int B, int Fmax, hipStream_t s) {
+    const int nfmax = 120 * Fmax + 1;
+    hipLaunchKernelGGL(istft_spec_kernel, dim3((nfmax + 255) / 256, 11, B), dim3(256), 0, s, cp, bs, ld, spec_ws,
+                       frames);
+    KX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(istft_ola_kernel, dim3((600 * Fmax + 255) / 256, B), dim3(256), 0, s, spec_ws, bs, ld, audio,
+                       audio_ld, frames);
+    KX_HIP(hipGetLastError());
+}
+
+}  // namespace kx

@@ -1,0 +1,160 @@
+// Internal declarations shared by the kokorox_hip translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace kx {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define KX_HIP(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            throw kx::Error(3, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" +  \
+                                   __FILE__ + ":" + std::to_string(__LINE__) + ")");       \
+    } while (0)
+
+#define KX_REQUIRE(cond, msg)                                 \
+    do {                                                      \
+        if (!(cond)) throw kx::Error(1, std::string(msg));    \
+    } while (0)
+
+// Valid length of utterance b for a tensor = lens[b] * mul + add (lens = tokens or frames).
+struct LenMap {
+    const int* lens;
+    int mul, add;
+};
+
+// ---- conv1d as implicit GEMM on the f32 MFMA (conv_mfma.hip) -------------------------
+constexpr int CONV_CK = 8;  // input channels per K-chunk
+
+enum ConvAct { ACT_NONE = 0, ACT_LEAKY = 1, ACT_SNAKE = 2 };
+enum ConvStore { ST_NORMAL = 0, ST_TMAJOR = 1, ST_UPSCATTER = 2 };
+enum ConvEpi { EPI_NONE = 0, EPI_GELU_NEW = 1 };
+
+struct ConvArgs {
+    // input [B][Cin][x_ld]
+    const float* x;
+    long x_bs;
+    int x_ld;
+    int Cin;
+    LenMap in_len;   // valid (virtual, after in_up2) input length
+    LenMap out_len;  // valid output length (ST_UPSCATTER: un-shifted upsampled length)
+    // packed weights [co_tile][chunk][k][8][BM] and bias [Cout]
+    const float* w;
+    const float* bias;
+    // optional per (b, ci) affine (x - mean) * scale + shift, each [B][n_bs]
+    const float* nmean;
+    const float* nscale;
+    const float* nshift;
+    int n_bs;
+    int act;
+    float slope;
+    const float* alpha;  // snake, [Cin]
+    int K, dil, stride, pad;
+    int in_up2;  // read x[p >> 1] (nearest x2 upsample of the input)
+    int Cout;    // GEMM rows (ST_UPSCATTER: up_s * up_cout)
+    int n_chunks;
+    // output [B][Cout][y_ld] (ST_TMAJOR: [B][L][y_ld])
+    float* y;
+    long y_bs;
+    int y_ld;
+    const float* resid;
+    long r_bs;
+    int r_ld;
+    int accum;
+    float out_mul;
+    float out_div;
+    int epi;
+    int store;
+    int up_s, up_pad, up_off, up_reflect, up_cout;
+};
+
+struct ConvShape {
+    int BM;  // 128, 64 or 32
+};
+inline int conv_pick_bm(int rows) { return rows >= 128 ? 128 : (rows > 32 ? 64 : 32); }
+inline int conv_bn(int BM) { return BM == 128 ? 128 : 256; }
+
+void launch_conv1d(const ConvArgs& a, int BM, int B, int max_cols, hipStream_t s);
+
+// weight repack: canonical layouts -> [co_tile][chunk][k][8][BM]
+struct PackSrc {
+    const float* p[3];  // up to three row-concatenated sources, each [rows_i][Cin][K]
+    int rows[3];
+};
+void launch_pack_conv(const PackSrc& src, float* dst, int Cout, int Cin, int K, int BM, hipStream_t s);
+// ConvTranspose1d weight [Cin][Cout][k], k == 2*s  ->  polyphase GEMM rows (p, co), 2 taps
+void launch_pack_convT(const float* w, float* dst, int Cin, int Cout, int s, int BM, hipStream_t s_);
+size_t packed_conv_floats(int rows, int Cin, int K, int BM);
+
+// ---- everything else (kernels_misc.hip) ----------------------------------------------
+void launch_vec_add(const float* a, const float* b, float* out, int n, hipStream_t s);
+void launch_transpose_whh(const float* whh, float* out, hipStream_t s);  // [1024][256] -> [256][1024]
+
+void launch_albert_embed(const int64_t* ids, long ids_stride, const float* word, const float* type0,
+                         const float* pos, float* out, long bs, int ld, const int* lens, int B, int Tmax,
+                         hipStream_t s);
+void launch_embed(const int64_t* ids, long ids_stride, const float* table, int C, float* out, long bs, int ld,
+                  const int* lens, int B, int Tmax, hipStream_t s);
+
+enum LnMode { LN_PLAIN = 0, LN_AFFINE = 1, LN_ADA = 2 };
+// channel layer-norm over C rows of [B][C][ld], in place allowed. ADA: g/be are [B][g_bs], (1+g)*xhat+be
+void launch_layernorm_ch(const float* x, float* y, long bs, int ld, int C, LenMap len, int B, int Lmax,
+                         float eps, int mode, const float* g, const float* be, int g_bs, float leaky,
+                         hipStream_t s);
+
+void launch_attention(const float* qkv, long bs, int ld, float* ctx, long cbs, int cld, const int* lens, int B,
+                      int Tmax, hipStream_t s);
+
+struct FcDesc {
+    const float* w;  // [n_out][128]
+    const float* b;  // [n_out]
+    int n_out;
+    int style_off;  // 0 or 128 within the 256-float style row
+    long out_off;   // into the gamma/beta arena, per utterance
+};
+void launch_style_fc(const FcDesc* d_desc, int n_desc, const float* styles, float* out, long out_bs, int B,
+                     hipStream_t s);
+
+// instance-norm statistics of [B][C][ld] rows -> mean, scale = rstd*(1+gamma), shift = beta
+void launch_in_stats(const float* x, long bs, int ld, int C, LenMap len, int B, const float* gb, long gb_bs,
+                     float* mean, float* scale, float* shift, int n_bs, hipStream_t s);
+
+void launch_fill_style_rows(float* dst, long bs, int ld, int row0, const float* styles, int style_off,
+                            const int* lens, int B, int Tmax, hipStream_t s);
+void launch_copy_rows(const float* src, long sbs, int sld, float* dst, long dbs, int dld, int rows, LenMap len,
+                      int B, int Lmax, hipStream_t s);
+
+void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, float* y, long y_bs, int y_ld,
+                 LenMap len, int B, hipStream_t s);
+
+void launch_duration(const float* logits, long bs, int ld, const float* speeds, int n_speed, const int* lens,
+                     const int* pinned, int n_pinned, int* dur, int* frames, int* idx, int idx_ld, int B,
+                     hipStream_t s);
+void launch_gather_cols(const float* src, long sbs, int sld, float* dst, long dbs, int dld, int C,
+                        const int* idx, int idx_ld, const int* frames, int B, int Fmax, hipStream_t s);
+
+// AdainResBlk1d "pool": leaky(norm(x)) -> depth-wise ConvTranspose1d(k3,s2,p1,op1)
+void launch_pool_up2(const float* x, long xbs, int xld, int C, const float* mean, const float* scale,
+                     const float* shift, int n_bs, float slope, const float* w, const float* bias, float* y,
+                     long ybs, int yld, LenMap in_len, int B, int Lmax_in, hipStream_t s);
+
+void launch_source(const float* f0, long f0_bs, const int* frames, int B, int Fmax, const float* lin_w,
+                   const float* lin_b, uint64_t seed, uint64_t utt_base, int noise_off, float* phase_ws,
+                   float* har, long har_bs, hipStream_t s);
+void launch_stft(const float* har_src, long hs_bs, float* har, long bs, int ld, const int* frames, int B,
+                 int Fmax, hipStream_t s);
+void launch_istft_head(const float* cp, long bs, int ld, float* spec_ws, float* audio, long audio_ld,
+                       const int* frames, int B, int Fmax, hipStream_t s);
+void init_dft_tables();
+
+}  // namespace kx

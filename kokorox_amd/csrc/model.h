@@ -1,0 +1,166 @@
+// Host-side model object behind the C ABI (include/kokorox_hip.h).
+#pragma once
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kx_common.h"
+
+namespace kx {
+
+struct TensorInfo {
+    size_t offset = 0, nbytes = 0;
+    int ndim = 0;
+    int dims[4] = {0, 0, 0, 0};
+};
+
+struct ConvW {
+    const float* w = nullptr;     // packed [co_tile][chunk][k][8][BM]
+    const float* bias = nullptr;  // [Cout] or null
+    int rows = 0, Cin = 0, K = 0, BM = 0, n_chunks = 0;
+    int up_s = 0, up_cout = 0;  // polyphase transposed conv
+};
+
+struct LstmW {
+    ConvW ih;                     // rows 2048 = [fwd i f g o | rev i f g o], bias = b_ih + b_hh
+    const float* whhT = nullptr;  // [2][256][1024]
+};
+
+// bump allocator over one device allocation; `measure` mode only counts
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0;
+    bool measure = false;
+    void* alloc(size_t bytes) {
+        const size_t a = (off + 255) & ~size_t(255);
+        off = a + bytes;
+        if (measure) return nullptr;
+        if (off > cap) throw Error(3, "arena overflow (internal sizing bug)");
+        return base + a;
+    }
+    float* f(size_t n) { return static_cast<float*>(alloc(n * sizeof(float))); }
+    int* i(size_t n) { return static_cast<int*>(alloc(n * sizeof(int))); }
+};
+
+struct Tap {
+    std::vector<float> data;  // [B][C][ld]
+    int B = 0, C = 0, ld = 0;
+    std::vector<int> L;
+};
+
+// activation view: [B][C][ld], utterance b valid for len.lens[b]*len.mul+len.add columns
+struct T {
+    float* p = nullptr;
+    long bs = 0;
+    int ld = 0;
+    int C = 0;
+    LenMap len{nullptr, 1, 0};
+    int Lmax = 0;
+    T rows(int r0, int n) const {
+        T t = *this;
+        t.p = p + (long)r0 * ld;
+        t.C = n;
+        return t;
+    }
+};
+
+struct ConvOpts {
+    const float* nmean = nullptr;
+    const float* nscale = nullptr;
+    const float* nshift = nullptr;
+    int act = ACT_NONE;
+    float slope = 0.f;
+    const float* alpha = nullptr;
+    int dil = 1, stride = 1, pad = 0, in_up2 = 0;
+    const T* resid = nullptr;
+    int accum = 0;
+    float out_mul = 1.f, out_div = 1.f;
+    int epi = EPI_NONE;
+    int store = ST_NORMAL;
+    int up_pad = 0, up_off = 0, up_reflect = 0;
+    LenMap up_len{nullptr, 1, 0};  // ST_UPSCATTER: un-shifted output length
+};
+
+class Model {
+  public:
+    Model(int device);
+    ~Model();
+    void load_file(const char* path);
+    void load_device_blob(const void* d_blob, size_t n);
+
+    void infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* lens_host, int B,
+                      const float* d_styles, const float* speeds_host, int n_speed, uint64_t seed, uint32_t flags,
+                      float* d_audio, int64_t audio_ld, int32_t* d_frames, int64_t* need_ld);
+    void infer_host(const int64_t* ids, int64_t t_stride, const int32_t* lens, int B, const float* styles,
+                    const float* speeds, int n_speed, uint64_t seed, uint32_t flags, float** out,
+                    int64_t* out_lens);
+    void sync();
+    void set_pinned(const int32_t* pattern, int n);
+    void profile_enable(bool on);
+    void profile_read(int64_t* launches, double* ms, double* flops);
+    const Tap* find_tap(const std::string& name) const;
+
+    std::mutex mu;
+    std::string last_error;
+    uint64_t utt_base = 0;
+    int device;
+
+  private:
+    void build();  // parse table, pack weights, style-fc descriptors
+    const float* wt(const std::string& name) const;
+    const TensorInfo& info(const std::string& name) const;
+    bool has(const std::string& name) const { return table_.count(name) != 0; }
+    float* dev_alloc(size_t floats);
+    ConvW make_conv(const std::string& name, bool bias = true);
+    ConvW make_conv_cat(const std::vector<std::string>& names);
+    ConvW make_convT(const std::string& name, int stride);
+    LstmW make_lstm(const std::string& name);
+    void add_fc(const std::string& key, const std::string& fc_name, int style_off);
+    long fc_off(const std::string& key) const;
+
+    void conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o);
+    void stats(const T& x, const std::string& fc_key);
+    void adain_resblk(const std::string& name, const T& x, const T& out, bool upsample, float* ws_a, float* ws_b,
+                      float* ws_c);
+    void adain_resblock1(const std::string& name, int k, const T& x, const T& xj, const T& t1, const T& out,
+                         int accum, float out_div);
+    void lstm(const LstmW& w, const T& in, const T& out, float* gx);
+    void tap(const char* name, const T& t);
+    void ensure_arena(Arena& a, size_t bytes);
+
+    hipStream_t stream_ = nullptr;
+    char* blob_ = nullptr;
+    size_t blob_bytes_ = 0;
+    std::map<std::string, TensorInfo> table_;
+    std::vector<void*> owned_;
+    std::map<std::string, ConvW> convs_;
+    std::map<std::string, LstmW> lstms_;
+    std::vector<FcDesc> fc_host_;
+    std::map<std::string, long> fc_off_;
+    FcDesc* fc_dev_ = nullptr;
+    long gb_total_ = 0;
+
+    Arena arenaT_, arenaF_, arenaIO_;
+    int* d_pinned_ = nullptr;
+    int n_pinned_ = 0;
+
+    // per-call state
+    int B_ = 0, Tmax_ = 0, Fmax_ = 0;
+    std::vector<int> hT_, hF_;
+    int *dT_ = nullptr, *dF_ = nullptr;
+    float* gb_ = nullptr;  // [B][gb_total_]
+    float *nmean_ = nullptr, *nscale_ = nullptr, *nshift_ = nullptr;
+    int n_bs_ = 0;
+    bool taps_on_ = false;
+    bool dry_ = false;  // sizing pass: allocate (count) but launch nothing
+    std::map<std::string, Tap> taps_;
+
+    bool prof_on_ = false;
+    std::vector<hipEvent_t> ev_;
+    size_t ev_used_ = 0;
+    double prof_flops_ = 0.0;
+    int64_t prof_launches_ = 0;
+};
+
+}  // namespace kx

@@ -1,0 +1,923 @@
+// Host side of the MI355X Kokoro-82M forward: weight registry + repacking, arenas and the
+// launch sequence that replaces `sess.run` (kokorox/src/onn/ort_koko.rs:79).  The graph is
+// the published Kokoro-82M; stage comments name the upstream module.
+#include "model.h"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace kx {
+
+static constexpr float RSQRT2 = 0.70710678118654752f;
+static inline int up4(int x) { return (x + 3) & ~3; }
+
+Model::Model(int dev) : device(dev) {
+    KX_HIP(hipSetDevice(device));
+    KX_HIP(hipStreamCreate(&stream_));
+    init_dft_tables();
+}
+
+Model::~Model() {
+    (void)hipSetDevice(device);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    for (void* p : owned_) (void)hipFree(p);
+    for (Arena* a : {&arenaT_, &arenaF_, &arenaIO_})
+        if (a->base) (void)hipFree(a->base);
+    if (blob_) (void)hipFree(blob_);
+    for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+// ---- weight container ------------------------------------------------------------------------
+static void parse_table(const unsigned char* hdr, size_t hdr_bytes, size_t total,
+                        std::map<std::string, TensorInfo>& table) {
+    uint32_t n;
+    memcpy(&n, hdr + 8, 4);
+    if (64 + (size_t)n * 128 > hdr_bytes) throw Error(2, "weight blob: truncated tensor table");
+    for (uint32_t i = 0; i < n; ++i) {
+        const unsigned char* e = hdr + 64 + (size_t)i * 128;
+        char name[89];
+        memcpy(name, e, 88);
+        name[88] = 0;
+        uint32_t dt, nd, dims[4];
+        uint64_t off, nb;
+        memcpy(&dt, e + 88, 4);
+        memcpy(&nd, e + 92, 4);
+        memcpy(dims, e + 96, 16);
+        memcpy(&off, e + 112, 8);
+        memcpy(&nb, e + 120, 8);
+        if (dt != 0 || nd > 4 || off + nb > total || (off & 255)) throw Error(2, std::string("weight blob: bad entry ") + name);
+        TensorInfo ti;
+        ti.offset = off;
+        ti.nbytes = nb;
+        ti.ndim = (int)nd;
+        size_t cnt = 1;
+        for (int k = 0; k < (int)nd; ++k) {
+            ti.dims[k] = (int)dims[k];
+            cnt *= dims[k];
+        }
+        if (cnt * 4 != nb) throw Error(2, std::string("weight blob: size mismatch ") + name);
+        table[name] = ti;
+    }
+}
+
+static size_t check_header(const unsigned char* h, size_t have) {
+    if (have < 64 || memcmp(h, "KXHIPW01", 8) != 0) throw Error(2, "weight blob: bad magic (expected KXHIPW01)");
+    uint64_t total;
+    memcpy(&total, h + 24, 8);
+    return (size_t)total;
+}
+
+void Model::load_file(const char* path) {
+    KX_REQUIRE(path && *path, "kx_create: empty weights path");
+    FILE* f = fopen(path, "rb");
+    if (!f) throw Error(2, std::string("cannot open weight file: ") + path);
+    fseek(f, 0, SEEK_END);
+    const size_t n = (size_t)ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<unsigned char> host(n);
+    const size_t got = fread(host.data(), 1, n, f);
+    fclose(f);
+    if (got != n) throw Error(2, std::string("short read on weight file: ") + path);
+    const size_t total = check_header(host.data(), n);
+    if (total != n) throw Error(2, "weight blob: file size does not match header");
+    parse_table(host.data(), n, total, table_);
+    KX_HIP(hipSetDevice(device));
+    KX_HIP(hipMalloc((void**)&blob_, n));
+    blob_bytes_ = n;
+    KX_HIP(hipMemcpy(blob_, host.data(), n, hipMemcpyHostToDevice));
+    build();
+}
+
+void Model::load_device_blob(const void* d_blob, size_t n) {
+    KX_REQUIRE(d_blob && n >= 64, "kx_create_from_device_blob: empty blob");
+    KX_HIP(hipSetDevice(device));
+    unsigned char h64[64];
+    KX_HIP(hipMemcpy(h64, d_blob, 64, hipMemcpyDeviceToHost));
+    const size_t total = check_header(h64, 64);
+    if (total != n) throw Error(2, "weight blob: size does not match header");
+    uint32_t nt;
+    memcpy(&nt, h64 + 8, 4);
+    const size_t hdr_bytes = 64 + (size_t)nt * 128;
+    if (hdr_bytes > n) throw Error(2, "weight blob: truncated tensor table");
+    std::vector<unsigned char> hdr(hdr_bytes);
+    KX_HIP(hipMemcpy(hdr.data(), d_blob, hdr_bytes, hipMemcpyDeviceToHost));
+    parse_table(hdr.data(), hdr_bytes, total, table_);
+    KX_HIP(hipMalloc((void**)&blob_, n));
+    blob_bytes_ = n;
+    KX_HIP(hipMemcpy(blob_, d_blob, n, hipMemcpyDeviceToDevice));
+    build();
+}
+
+const TensorInfo& Model::info(const std::string& name) const {
+    auto it = table_.find(name);
+    if (it == table_.end()) throw Error(2, "weight blob: missing tensor " + name);
+    return it->second;
+}
+const float* Model::wt(const std::string& name) const {
+    return reinterpret_cast<const float*>(blob_ + info(name).offset);
+}
+float* Model::dev_alloc(size_t floats) {
+    void* p = nullptr;
+    KX_HIP(hipMalloc(&p, floats * sizeof(float)));
+    owned_.push_back(p);
+    return static_cast<float*>(p);
+}
+
+ConvW Model::make_conv(const std::string& name, bool bias) {
+    const TensorInfo& ti = info(name + ".weight");
+    ConvW c;
+    c.rows = ti.dims[0];
+    c.Cin = ti.dims[1];
+    c.K = ti.ndim >= 3 ? ti.dims[2] : 1;
+    c.BM = conv_pick_bm(c.rows);
+    c.n_chunks = (c.Cin + CONV_CK - 1) / CONV_CK;
+    float* p = dev_alloc(packed_conv_floats(c.rows, c.Cin, c.K, c.BM));
+    PackSrc src{{wt(name + ".weight"), nullptr, nullptr}, {c.rows, 0, 0}};
+    launch_pack_conv(src, p, c.rows, c.Cin, c.K, c.BM, stream_);
+    c.w = p;
+    c.bias = (bias && has(name + ".bias")) ? wt(name + ".bias") : nullptr;
+    return c;
+}
+
+ConvW Model::make_conv_cat(const std::vector<std::string>& names) {
+    KX_REQUIRE(names.size() <= 3 && !names.empty(), "make_conv_cat");
+    ConvW c;
+    PackSrc src{{nullptr, nullptr, nullptr}, {0, 0, 0}};
+    for (size_t i = 0; i < names.size(); ++i) {
+        const TensorInfo& ti = info(names[i] + ".weight");
+        src.p[i] = wt(names[i] + ".weight");
+        src.rows[i] = ti.dims[0];
+        c.rows += ti.dims[0];
+        c.Cin = ti.dims[1];
+        c.K = ti.ndim >= 3 ? ti.dims[2] : 1;
+    }
+    c.BM = conv_pick_bm(c.rows);
+    c.n_chunks = (c.Cin + CONV_CK - 1) / CONV_CK;
+    float* p = dev_alloc(packed_conv_floats(c.rows, c.Cin, c.K, c.BM));
+    launch_pack_conv(src, p, c.rows, c.Cin, c.K, c.BM, stream_);
+    c.w = p;
+    float* bias = dev_alloc(c.rows);
+    int r0 = 0;
+    for (size_t i = 0; i < names.size(); ++i) {
+        KX_HIP(hipMemcpyAsync(bias + r0, wt(names[i] + ".bias"), (size_t)src.rows[i] * 4, hipMemcpyDeviceToDevice,
+                              stream_));
+        r0 += src.rows[i];
+    }
+    c.bias = bias;
+    return c;
+}
+
+ConvW Model::make_convT(const std::string& name, int stride) {
+    const TensorInfo& ti = info(name + ".weight");  // [Cin][Cout][k]
+    KX_REQUIRE(ti.dims[2] == 2 * stride, "transposed conv: only k == 2*stride is supported");
+    ConvW c;
+    c.Cin = ti.dims[0];
+    c.up_cout = ti.dims[1];
+    c.up_s = stride;
+    c.rows = stride * c.up_cout;
+    c.K = 2;
+    c.BM = conv_pick_bm(c.rows);
+    c.n_chunks = (c.Cin + CONV_CK - 1) / CONV_CK;
+    float* p = dev_alloc(packed_conv_floats(c.rows, c.Cin, 2, c.BM));
+    launch_pack_convT(wt(name + ".weight"), p, c.Cin, c.up_cout, stride, c.BM, stream_);
+    c.w = p;
+    c.bias = wt(name + ".bias");
+    return c;
+}
+
+LstmW Model::make_lstm(const std::string& name) {
+    LstmW l;
+    const TensorInfo& ti = info(name + ".weight_ih_l0");
+    ConvW& c = l.ih;
+    c.rows = 2048;
+    c.Cin = ti.dims[1];
+    c.K = 1;
+    c.BM = 128;
+    c.n_chunks = (c.Cin + CONV_CK - 1) / CONV_CK;
+    float* p = dev_alloc(packed_conv_floats(2048, c.Cin, 1, 128));
+    PackSrc src{{wt(name + ".weight_ih_l0"), wt(name + ".weight_ih_l0_reverse"), nullptr}, {1024, 1024, 0}};
+    launch_pack_conv(src, p, 2048, c.Cin, 1, 128, stream_);
+    c.w = p;
+    float* bias = dev_alloc(2048);
+    launch_vec_add(wt(name + ".bias_ih_l0"), wt(name + ".bias_hh_l0"), bias, 1024, stream_);
+    launch_vec_add(wt(name + ".bias_ih_l0_reverse"), wt(name + ".bias_hh_l0_reverse"), bias + 1024, 1024, stream_);
+    c.bias = bias;
+    float* wh = dev_alloc(2 * 256 * 1024);
+    launch_transpose_whh(wt(name + ".weight_hh_l0"), wh, stream_);
+    launch_transpose_whh(wt(name + ".weight_hh_l0_reverse"), wh + 256 * 1024, stream_);
+    l.whhT = wh;
+    return l;
+}
+
+void Model::add_fc(const std::string& key, const std::string& fc_name, int style_off) {
+    const TensorInfo& ti = info(fc_name + ".weight");
+    KX_REQUIRE(ti.dims[1] == 128, "style fc: expected 128 inputs");
+    FcDesc d;
+    d.w = wt(fc_name + ".weight");
+    d.b = wt(fc_name + ".bias");
+    d.n_out = ti.dims[0];
+    d.style_off = style_off;
+    d.out_off = gb_total_;
+    fc_off_[key] = gb_total_;
+    gb_total_ += d.n_out;
+    fc_host_.push_back(d);
+}
+long Model::fc_off(const std::string& key) const {
+    auto it = fc_off_.find(key);
+    if (it == fc_off_.end()) throw Error(4, "internal: unknown style fc " + key);
+    return it->second;
+}
+
+void Model::build() {
+    const std::string L = "bert.encoder.albert_layer_groups.0.albert_layers.0.";
+    convs_["bert.map"] = make_conv("bert.encoder.embedding_hidden_mapping_in");
+    convs_["bert.qkv"] = make_conv_cat({L + "attention.query", L + "attention.key", L + "attention.value"});
+    convs_["bert.dense"] = make_conv(L + "attention.dense");
+    convs_["bert.ffn"] = make_conv(L + "ffn");
+    convs_["bert.ffn_out"] = make_conv(L + "ffn_output");
+    convs_["bert_encoder"] = make_conv("bert_encoder");
+    for (int i = 0; i < 3; ++i) {
+        const std::string n = "predictor.text_encoder.lstms." + std::to_string(2 * i);
+        lstms_[n] = make_lstm(n);
+        add_fc("dur_enc." + std::to_string(i), "predictor.text_encoder.lstms." + std::to_string(2 * i + 1) + ".fc", 128);
+    }
+    lstms_["predictor.lstm"] = make_lstm("predictor.lstm");
+    lstms_["predictor.shared"] = make_lstm("predictor.shared");
+    lstms_["text_encoder.lstm"] = make_lstm("text_encoder.lstm");
+    convs_["duration_proj"] = make_conv("predictor.duration_proj.linear_layer");
+    auto reg_resblk = [&](const std::string& n, int style_off) {
+        convs_[n + ".conv1"] = make_conv(n + ".conv1");
+        convs_[n + ".conv2"] = make_conv(n + ".conv2");
+        if (has(n + ".conv1x1.weight")) convs_[n + ".conv1x1"] = make_conv(n + ".conv1x1", false);
+        add_fc(n + ".norm1", n + ".norm1.fc", style_off);
+        add_fc(n + ".norm2", n + ".norm2.fc", style_off);
+    };
+    for (const char* br : {"F0", "N"}) {
+        for (int i = 0; i < 3; ++i) reg_resblk(std::string("predictor.") + br + "." + std::to_string(i), 128);
+        convs_[std::string("predictor.") + br + "_proj"] = make_conv(std::string("predictor.") + br + "_proj");
+    }
+    for (int i = 0; i < 3; ++i)
+        convs_["text_encoder.cnn." + std::to_string(i)] = make_conv("text_encoder.cnn." + std::to_string(i) + ".0");
+    reg_resblk("decoder.encode", 0);
+    for (int i = 0; i < 4; ++i) reg_resblk("decoder.decode." + std::to_string(i), 0);
+    convs_["decoder.F0_conv"] = make_conv("decoder.F0_conv");
+    convs_["decoder.N_conv"] = make_conv("decoder.N_conv");
+    convs_["decoder.asr_res"] = make_conv("decoder.asr_res.0");
+    const std::string G = "decoder.generator.";
+    auto reg_resblock1 = [&](const std::string& n) {
+        for (int i = 0; i < 3; ++i) {
+            const std::string s = std::to_string(i);
+            convs_[n + ".convs1." + s] = make_conv(n + ".convs1." + s);
+            convs_[n + ".convs2." + s] = make_conv(n + ".convs2." + s);
+            add_fc(n + ".adain1." + s, n + ".adain1." + s + ".fc", 0);
+            add_fc(n + ".adain2." + s, n + ".adain2." + s + ".fc", 0);
+        }
+    };
+    for (int i = 0; i < 2; ++i) {
+        convs_[G + "noise_convs." + std::to_string(i)] = make_conv(G + "noise_convs." + std::to_string(i));
+        reg_resblock1(G + "noise_res." + std::to_string(i));
+    }
+    convs_[G + "ups.0"] = make_convT(G + "ups.0", 10);
+    convs_[G + "ups.1"] = make_convT(G + "ups.1", 6);
+    for (int i = 0; i < 6; ++i) reg_resblock1(G + "resblocks." + std::to_string(i));
+    convs_[G + "conv_post"] = make_conv(G + "conv_post");
+
+    KX_HIP(hipMalloc((void**)&fc_dev_, fc_host_.size() * sizeof(FcDesc)));
+    owned_.push_back(fc_dev_);
+    KX_HIP(hipMemcpyAsync(fc_dev_, fc_host_.data(), fc_host_.size() * sizeof(FcDesc), hipMemcpyHostToDevice, stream_));
+    KX_HIP(hipStreamSynchronize(stream_));
+}
+
+// ---- helpers ------------------------------------------------------------------------------------
+void Model::ensure_arena(Arena& a, size_t bytes) {
+    if (bytes <= a.cap) return;
+    KX_HIP(hipStreamSynchronize(stream_));
+    if (a.base) KX_HIP(hipFree(a.base));
+    a.base = nullptr;
+    a.cap = 0;
+    const size_t want = bytes + bytes / 8 + (1 << 20);
+    KX_HIP(hipMalloc((void**)&a.base, want));
+    a.cap = want;
+}
+
+
+
+void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
+    if (dry_) return;
+    ConvArgs a{};
+    a.x = in.p;
+    a.x_bs = in.bs;
+    a.x_ld = in.ld;
+    a.Cin = w.Cin;
+    KX_REQUIRE(in.C == w.Cin, "internal: conv Cin mismatch");
+    a.in_len = in.len;
+    if (o.in_up2) {
+        a.in_len.mul *= 2;
+        a.in_len.add *= 2;
+    }
+    a.out_len = (o.store == ST_UPSCATTER) ? o.up_len : out.len;
+    a.w = w.w;
+    a.bias = w.bias;
+    a.nmean = o.nmean;
+    a.nscale = o.nscale;
+    a.nshift = o.nshift;
+    a.n_bs = n_bs_;
+    a.act = o.act;
+    a.slope = o.slope;
+    a.alpha = o.alpha;
+    a.K = w.K;
+    a.dil = o.dil;
+    a.stride = o.stride;
+    a.pad = o.pad;
+    a.in_up2 = o.in_up2;
+    a.Cout = w.rows;
+    a.n_chunks = w.n_chunks;
+    a.y = out.p;
+    a.y_bs = out.bs;
+    a.y_ld = out.ld;
+    if (o.resid) {
+        a.resid = o.resid->p;
+        a.r_bs = o.resid->bs;
+        a.r_ld = o.resid->ld;
+    }
+    a.accum = o.accum;
+    a.out_mul = o.out_mul;
+    a.out_div = o.out_div;
+    a.epi = o.epi;
+    a.store = o.store;
+    a.up_s = w.up_s;
+    a.up_pad = o.up_pad;
+    a.up_off = o.up_off;
+    a.up_reflect = o.up_reflect;
+    a.up_cout = w.up_cout ? w.up_cout : 1;
+    const int max_cols = (o.store == ST_UPSCATTER) ? in.Lmax + 1 : out.Lmax;
+    if (prof_on_) {
+        const LenMap& lm = (o.store == ST_UPSCATTER) ? in.len : out.len;
+        const std::vector<int>& hl = (lm.lens == dT_) ? hT_ : hF_;
+        double cols = 0;
+        for (int b = 0; b < B_; ++b) cols += (double)hl[b] * lm.mul + lm.add + (o.store == ST_UPSCATTER ? 1 : 0);
+        prof_flops_ += 2.0 * w.rows * w.Cin * w.K * cols;
+        prof_launches_ += 1;
+        if (ev_used_ + 2 > ev_.size()) {
+            for (int i = 0; i < 64; ++i) {
+                hipEvent_t e;
+                KX_HIP(hipEventCreate(&e));
+                ev_.push_back(e);
+            }
+        }
+        KX_HIP(hipEventRecord(ev_[ev_used_], stream_));
+        launch_conv1d(a, w.BM, B_, max_cols, stream_);
+        KX_HIP(hipEventRecord(ev_[ev_used_ + 1], stream_));
+        ev_used_ += 2;
+    } else {
+        launch_conv1d(a, w.BM, B_, max_cols, stream_);
+    }
+}
+
+void Model::stats(const T& x, const std::string& fc_key) {
+    if (dry_) return;
+    launch_in_stats(x.p, x.bs, x.ld, x.C, x.len, B_, gb_ + fc_off(fc_key), gb_total_, nmean_, nscale_, nshift_, n_bs_,
+                    stream_);
+}
+
+void Model::tap(const char* name, const T& t) {
+    if (!taps_on_ || dry_) return;
+    KX_HIP(hipStreamSynchronize(stream_));
+    Tap tp;
+    tp.B = B_;
+    tp.C = t.C;
+    tp.ld = t.ld;
+    tp.data.resize((size_t)B_ * t.C * t.ld);
+    const std::vector<int>& hl = (t.len.lens == dT_) ? hT_ : hF_;
+    for (int b = 0; b < B_; ++b) {
+        tp.L.push_back(hl[b] * t.len.mul + t.len.add);
+        KX_HIP(hipMemcpy(tp.data.data() + (size_t)b * t.C * t.ld, t.p + (long)b * t.bs, (size_t)t.C * t.ld * 4,
+                         hipMemcpyDeviceToHost));
+    }
+    taps_[name] = std::move(tp);
+}
+
+const Tap* Model::find_tap(const std::string& name) const {
+    auto it = taps_.find(name);
+    return it == taps_.end() ? nullptr : &it->second;
+}
+
+void Model::lstm(const LstmW& w, const T& in, const T& out, float* gx) {
+    if (dry_) return;
+    T g;
+    g.p = gx;
+    g.bs = (long)in.Lmax * 2048;
+    g.ld = 2048;
+    g.C = 2048;
+    g.len = in.len;
+    g.Lmax = in.Lmax;
+    ConvOpts o;
+    o.store = ST_TMAJOR;
+    conv(w.ih, in, g, o);
+    launch_lstm(gx, g.bs, 2048, w.whhT, out.p, out.bs, out.ld, in.len, B_, stream_);
+}
+
+// AdainResBlk1d (istftnet.py): out = (conv2(act(norm2(conv1(pool(act(norm1(x))))))) + shortcut(x)) / sqrt(2)
+void Model::adain_resblk(const std::string& name, const T& x, const T& out, bool upsample, float* ws_a, float* ws_b,
+                         float* ws_c) {
+    const ConvW& c1 = convs_.at(name + ".conv1");
+    const ConvW& c2 = convs_.at(name + ".conv2");
+    T t1 = out;
+    t1.p = ws_a;
+    t1.bs = (long)out.C * out.ld;
+    stats(x, name + ".norm1");
+    if (!upsample) {
+        ConvOpts o;
+        o.nmean = nmean_; o.nscale = nscale_; o.nshift = nshift_;
+        o.act = ACT_LEAKY; o.slope = 0.2f; o.pad = 1;
+        conv(c1, x, t1, o);
+    } else {
+        T p = out;
+        p.p = ws_c;
+        p.C = x.C;
+        p.bs = (long)x.C * out.ld;
+        if (!dry_)
+            launch_pool_up2(x.p, x.bs, x.ld, x.C, nmean_, nscale_, nshift_, n_bs_, 0.2f, wt(name + ".pool.weight"),
+                            wt(name + ".pool.bias"), p.p, p.bs, p.ld, x.len, B_, x.Lmax, stream_);
+        ConvOpts o;
+        o.pad = 1;
+        conv(c1, p, t1, o);
+    }
+    stats(t1, name + ".norm2");
+    T sc = out;
+    const T* res = &x;
+    if (convs_.count(name + ".conv1x1")) {
+        sc.p = ws_b;
+        sc.bs = (long)out.C * out.ld;
+        ConvOpts o;
+        o.in_up2 = upsample ? 1 : 0;
+        conv(convs_.at(name + ".conv1x1"), x, sc, o);
+        res = &sc;
+    } else {
+        KX_REQUIRE(!upsample && x.C == out.C, "internal: identity shortcut needs equal shapes");
+    }
+    ConvOpts o;
+    o.nmean = nmean_; o.nscale = nscale_; o.nshift = nshift_;
+    o.act = ACT_LEAKY; o.slope = 0.2f; o.pad = 1;
+    o.resid = res;
+    o.out_mul = RSQRT2;
+    conv(c2, t1, out, o);
+}
+
+// AdaINResBlock1 with Snake1D (istftnet.py).  x is read-only; xj/t1 are scratch of x's shape;
+// the third iteration lands in `out` (optionally accumulated and divided: mean over kernels).
+void Model::adain_resblock1(const std::string& name, int k, const T& x, const T& xj, const T& t1, const T& out,
+                            int accum, float out_div) {
+    static const int dils[3] = {1, 3, 5};
+    for (int i = 0; i < 3; ++i) {
+        const std::string s = std::to_string(i);
+        const T& cur = (i == 0) ? x : xj;
+        const T& dst = (i == 2) ? out : xj;
+        stats(cur, name + ".adain1." + s);
+        ConvOpts o1;
+        o1.nmean = nmean_; o1.nscale = nscale_; o1.nshift = nshift_;
+        o1.act = ACT_SNAKE;
+        o1.alpha = dry_ ? nullptr : wt(name + ".alpha1." + s);
+        o1.dil = dils[i];
+        o1.pad = (k * dils[i] - dils[i]) / 2;
+        conv(convs_.at(name + ".convs1." + s), cur, t1, o1);
+        stats(t1, name + ".adain2." + s);
+        ConvOpts o2;
+        o2.nmean = nmean_; o2.nscale = nscale_; o2.nshift = nshift_;
+        o2.act = ACT_SNAKE;
+        o2.alpha = dry_ ? nullptr : wt(name + ".alpha2." + s);
+        o2.pad = (k - 1) / 2;
+        o2.resid = &cur;
+        if (i == 2) {
+            o2.accum = accum;
+            o2.out_div = out_div;
+        }
+        conv(convs_.at(name + ".convs2." + s), t1, dst, o2);
+    }
+}
+
+void Model::sync() {
+    KX_HIP(hipSetDevice(device));
+    KX_HIP(hipStreamSynchronize(stream_));
+}
+
+void Model::set_pinned(const int32_t* pattern, int n) {
+    KX_HIP(hipSetDevice(device));
+    KX_HIP(hipStreamSynchronize(stream_));
+    n_pinned_ = 0;
+    if (n <= 0) return;
+    KX_REQUIRE(pattern && n <= 512, "pinned durations: 1..512 entries");
+    for (int i = 0; i < n; ++i) KX_REQUIRE(pattern[i] >= 1 && pattern[i] <= 50, "pinned durations must be in 1..50");
+    if (!d_pinned_) {
+        KX_HIP(hipMalloc((void**)&d_pinned_, 512 * sizeof(int)));
+        owned_.push_back(d_pinned_);
+    }
+    KX_HIP(hipMemcpy(d_pinned_, pattern, n * sizeof(int), hipMemcpyHostToDevice));
+    n_pinned_ = n;
+}
+
+void Model::profile_enable(bool on) {
+    sync();
+    prof_on_ = on;
+    ev_used_ = 0;
+    prof_flops_ = 0;
+    prof_launches_ = 0;
+}
+
+void Model::profile_read(int64_t* launches, double* ms, double* flops) {
+    if (!prof_on_) throw Error(4, "profiling is not enabled");
+    sync();
+    double total = 0;
+    for (size_t i = 0; i + 1 < ev_used_; i += 2) {
+        float t = 0;
+        KX_HIP(hipEventElapsedTime(&t, ev_[i], ev_[i + 1]));
+        total += t;
+    }
+    *launches = prof_launches_;
+    *ms = total;
+    *flops = prof_flops_;
+    ev_used_ = 0;
+    prof_flops_ = 0;
+    prof_launches_ = 0;
+}
+
+// ---- the forward pass ---------------------------------------------------------------------------
+void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* lens_host, int B,
+                         const float* d_styles, const float* speeds_host, int n_speed, uint64_t seed, uint32_t flags,
+                         float* d_audio, int64_t audio_ld, int32_t* d_frames, int64_t* need_ld) {
+    KX_REQUIRE(B >= 1 && B <= 4096, "infer: batch must be 1..4096 (empty input is an error)");
+    KX_REQUIRE(d_ids && lens_host && d_styles && speeds_host, "infer: null argument");
+    KX_REQUIRE(n_speed == 1 || n_speed == B, "infer: n_speed must be 1 or B");
+    int Tmax = 0;
+    for (int b = 0; b < B; ++b) {
+        KX_REQUIRE(lens_host[b] >= 1 && lens_host[b] <= 512, "infer: token count must be 1..512");
+        KX_REQUIRE((int64_t)lens_host[b] <= t_stride, "infer: lens[b] exceeds the row stride");
+        if (lens_host[b] > Tmax) Tmax = lens_host[b];
+    }
+    for (int i = 0; i < n_speed; ++i) KX_REQUIRE(speeds_host[i] > 0.f, "infer: speed must be > 0");
+    KX_HIP(hipSetDevice(device));
+    B_ = B;
+    Tmax_ = Tmax;
+    taps_on_ = (flags & 2u) != 0;
+    taps_.clear();
+    hT_.assign(lens_host, lens_host + B);
+    hF_.assign(B, 0);
+    const int Tp = up4(Tmax);
+    const int idx_ld = Tmax * 50;
+    n_bs_ = 1104;
+    const int noise_off = (flags & 1u) ? 1 : 0;
+
+    // ===== front half: everything on the token axis ==========================================
+    float *emb, *h, *qkv, *ctx, *av, *ff, *dcat, *gxT, *xl, *logits, *te0, *te1, *t_en, *d_speeds;
+    int *dur, *idx;
+    auto planT = [&](Arena& A) {
+        A.off = 0;
+        dT_ = A.i(B);
+        dF_ = A.i(B);
+        d_speeds = A.f(B);
+        dur = A.i((size_t)B * 512);
+        idx = A.i((size_t)B * idx_ld);
+        gb_ = A.f((size_t)B * gb_total_);
+        nmean_ = A.f((size_t)B * n_bs_);
+        nscale_ = A.f((size_t)B * n_bs_);
+        nshift_ = A.f((size_t)B * n_bs_);
+        const size_t bt = (size_t)B * Tp;
+        emb = A.f(bt * 128);
+        h = A.f(bt * 768);
+        qkv = A.f(bt * 2304);
+        ctx = A.f(bt * 768);
+        av = A.f(bt * 768);
+        ff = A.f(bt * 2048);
+        dcat = A.f(bt * 640);
+        gxT = A.f(bt * 2048);
+        xl = A.f(bt * 512);
+        logits = A.f(bt * 50);
+        te0 = A.f(bt * 512);
+        te1 = A.f(bt * 512);
+        t_en = A.f(bt * 512);
+    };
+    arenaT_.measure = true;
+    planT(arenaT_);
+    const size_t needT = arenaT_.off;
+    arenaT_.measure = false;
+    ensure_arena(arenaT_, needT);
+    planT(arenaT_);
+
+    KX_HIP(hipMemcpyAsync(dT_, lens_host, B * sizeof(int), hipMemcpyHostToDevice, stream_));
+    KX_HIP(hipMemcpyAsync(d_speeds, speeds_host, n_speed * sizeof(float), hipMemcpyHostToDevice, stream_));
+    const LenMap LT{dT_, 1, 0};
+    auto TT = [&](float* p, int C) {
+        T t;
+        t.p = p; t.bs = (long)C * Tp; t.ld = Tp; t.C = C; t.len = LT; t.Lmax = Tmax;
+        return t;
+    };
+    launch_style_fc(fc_dev_, (int)fc_host_.size(), d_styles, gb_, gb_total_, B, stream_);
+
+    // --- PL-BERT (ALBERT, 12 passes over one shared layer) ---
+    const std::string E = "bert.embeddings.";
+    const std::string AL = "bert.encoder.albert_layer_groups.0.albert_layers.0.";
+    T t_emb = TT(emb, 128), t_h = TT(h, 768), t_qkv = TT(qkv, 2304), t_ctx = TT(ctx, 768), t_a = TT(av, 768),
+      t_f = TT(ff, 2048);
+    launch_albert_embed(d_ids, t_stride, wt(E + "word_embeddings.weight"), wt(E + "token_type_embeddings.weight"),
+                        wt(E + "position_embeddings.weight"), emb, t_emb.bs, Tp, dT_, B, Tmax, stream_);
+    launch_layernorm_ch(emb, emb, t_emb.bs, Tp, 128, LT, B, Tmax, 1e-12f, LN_AFFINE, wt(E + "LayerNorm.weight"),
+                        wt(E + "LayerNorm.bias"), 0, 0.f, stream_);
+    tap("bert.emb", t_emb);
+    conv(convs_.at("bert.map"), t_emb, t_h, ConvOpts{});
+    for (int l = 0; l < 12; ++l) {
+        conv(convs_.at("bert.qkv"), t_h, t_qkv, ConvOpts{});
+        launch_attention(qkv, t_qkv.bs, Tp, ctx, t_ctx.bs, Tp, dT_, B, Tmax, stream_);
+        ConvOpts od;
+        od.resid = &t_h;
+        conv(convs_.at("bert.dense"), t_ctx, t_a, od);
+        launch_layernorm_ch(av, av, t_a.bs, Tp, 768, LT, B, Tmax, 1e-12f, LN_AFFINE,
+                            wt(AL + "attention.LayerNorm.weight"), wt(AL + "attention.LayerNorm.bias"), 0, 0.f, stream_);
+        ConvOpts of;
+        of.epi = EPI_GELU_NEW;
+        conv(convs_.at("bert.ffn"), t_a, t_f, of);
+        ConvOpts oo;
+        oo.resid = &t_a;
+        conv(convs_.at("bert.ffn_out"), t_f, t_h, oo);
+        launch_layernorm_ch(h, h, t_h.bs, Tp, 768, LT, B, Tmax, 1e-12f, LN_AFFINE,
+                            wt(AL + "full_layer_layer_norm.weight"), wt(AL + "full_layer_layer_norm.bias"), 0, 0.f,
+                            stream_);
+        if (l == 0) tap("bert.layer0", t_h);
+    }
+    tap("bert.out", t_h);
+
+    // --- bert_encoder + DurationEncoder (3 x biLSTM + AdaLayerNorm) + duration head ---
+    T t_dcat = TT(dcat, 640);
+    T t_d512 = t_dcat.rows(0, 512);
+    conv(convs_.at("bert_encoder"), t_h, t_d512, ConvOpts{});
+    tap("d_en", t_d512);
+    launch_fill_style_rows(dcat, t_dcat.bs, Tp, 512, d_styles, 128, dT_, B, Tmax, stream_);
+    for (int i = 0; i < 3; ++i) {
+        lstm(lstms_.at("predictor.text_encoder.lstms." + std::to_string(2 * i)), t_dcat, t_d512, gxT);
+        const float* g = gb_ + fc_off("dur_enc." + std::to_string(i));
+        launch_layernorm_ch(dcat, dcat, t_dcat.bs, Tp, 512, LT, B, Tmax, 1e-5f, LN_ADA, g, g + 512, (int)gb_total_, 0.f,
+                            stream_);
+        tap(("dur_enc." + std::to_string(i)).c_str(), t_dcat);
+    }
+    T t_xl = TT(xl, 512), t_logits = TT(logits, 50);
+    lstm(lstms_.at("predictor.lstm"), t_dcat, t_xl, gxT);
+    tap("dur.lstm", t_xl);
+    conv(convs_.at("duration_proj"), t_xl, t_logits, ConvOpts{});
+    launch_duration(logits, t_logits.bs, Tp, d_speeds, n_speed, dT_, d_pinned_, n_pinned_, dur, dF_, idx, idx_ld, B,
+                    stream_);
+    KX_HIP(hipMemcpyAsync(hF_.data(), dF_, B * sizeof(int), hipMemcpyDeviceToHost, stream_));
+
+    // --- TextEncoder (embedding, 3 x conv k5 + LayerNorm + LeakyReLU, biLSTM) ---
+    T t_te0 = TT(te0, 512), t_te1 = TT(te1, 512), t_ten = TT(t_en, 512);
+    launch_embed(d_ids, t_stride, wt("text_encoder.embedding.weight"), 512, te0, t_te0.bs, Tp, dT_, B, Tmax, stream_);
+    T* cur = &t_te0;
+    T* nxt = &t_te1;
+    for (int i = 0; i < 3; ++i) {
+        ConvOpts o;
+        o.pad = 2;
+        conv(convs_.at("text_encoder.cnn." + std::to_string(i)), *cur, *nxt, o);
+        const std::string ln = "text_encoder.cnn." + std::to_string(i) + ".1.";
+        launch_layernorm_ch(nxt->p, nxt->p, nxt->bs, Tp, 512, LT, B, Tmax, 1e-5f, LN_AFFINE, wt(ln + "gamma"),
+                            wt(ln + "beta"), 0, 0.2f, stream_);
+        std::swap(cur, nxt);
+    }
+    tap("text_enc.cnn", *cur);
+    lstm(lstms_.at("text_encoder.lstm"), *cur, t_ten, gxT);
+    tap("text_enc.out", t_ten);
+
+    // ===== the one host round trip: predicted frame counts size everything downstream =========
+    KX_HIP(hipStreamSynchronize(stream_));
+    int Fmax = 0;
+    for (int b = 0; b < B; ++b) Fmax = hF_[b] > Fmax ? hF_[b] : Fmax;
+    Fmax_ = Fmax;
+    if (need_ld) *need_ld = (int64_t)600 * Fmax;
+    if (d_frames) KX_HIP(hipMemcpyAsync(d_frames, dF_, B * sizeof(int), hipMemcpyDeviceToDevice, stream_));
+    if (audio_ld < (int64_t)600 * Fmax || !d_audio)
+        throw Error(1, "infer: audio buffer too small, need ld >= " + std::to_string((long long)600 * Fmax));
+
+    // ===== back half: frame axis ==============================================================
+    const int F1p = up4(Fmax), F2p = up4(2 * Fmax), F20p = up4(20 * Fmax), F120p = up4(120 * Fmax + 1);
+    const LenMap LF1{dF_, 1, 0}, LF2{dF_, 2, 0}, LF20{dF_, 20, 0}, LF120{dF_, 120, 0}, LF121{dF_, 120, 1};
+    auto mk = [&](Arena& A, int C, int ld, LenMap len, int Lmax) {
+        T t;
+        t.p = A.f((size_t)B * C * ld);
+        t.bs = (long)C * ld; t.ld = ld; t.C = C; t.len = len; t.Lmax = Lmax;
+        return t;
+    };
+    auto back = [&](Arena& A) {
+        A.off = 0;
+        auto F1 = [&](int C) { return mk(A, C, F1p, LF1, Fmax); };
+        auto F2 = [&](int C) { return mk(A, C, F2p, LF2, 2 * Fmax); };
+        auto F20 = [&](int C) { return mk(A, C, F20p, LF20, 20 * Fmax); };
+        auto F121 = [&](int C) { return mk(A, C, F120p, LF121, 120 * Fmax + 1); };
+        // --- alignment expand + shared biLSTM + F0 / N predictors (ProsodyPredictor.F0Ntrain) ---
+        T en = F1(640);
+        if (!dry_) launch_gather_cols(dcat, t_dcat.bs, Tp, en.p, en.bs, en.ld, 640, idx, idx_ld, dF_, B, Fmax, stream_);
+        float* gxF = A.f((size_t)B * Fmax * 2048);
+        T xsh = F1(512);
+        lstm(lstms_.at("predictor.shared"), en, xsh, gxF);
+        tap("pred.shared", xsh);
+        T curves = F2(2);  // row 0 = F0 curve, row 1 = N curve, length 2F
+        for (int br = 0; br < 2; ++br) {
+            const std::string P = std::string("predictor.") + (br == 0 ? "F0" : "N");
+            T y0 = F1(512);
+            adain_resblk(P + ".0", xsh, y0, false, A.f((size_t)B * 512 * F1p), nullptr, nullptr);
+            T y1 = F2(256);
+            float* wa = A.f((size_t)B * 256 * F2p);
+            float* wb = A.f((size_t)B * 256 * F2p);
+            float* wc = A.f((size_t)B * 512 * F2p);
+            adain_resblk(P + ".1", y0, y1, true, wa, wb, wc);
+            T y2 = F2(256);
+            adain_resblk(P + ".2", y1, y2, false, A.f((size_t)B * 256 * F2p), nullptr, nullptr);
+            conv(convs_.at(P + "_proj"), y2, curves.rows(br, 1), ConvOpts{});
+        }
+        tap("pred.F0", curves.rows(0, 1));
+        tap("pred.N", curves.rows(1, 1));
+        // --- Decoder (istftnet.py Decoder.forward) ---
+        T xcat0 = F1(514);
+        if (!dry_)
+            launch_gather_cols(t_en, t_ten.bs, Tp, xcat0.p, xcat0.bs, xcat0.ld, 512, idx, idx_ld, dF_, B, Fmax, stream_);
+        {
+            ConvOpts o;
+            o.stride = 2;
+            o.pad = 1;
+            conv(convs_.at("decoder.F0_conv"), curves.rows(0, 1), xcat0.rows(512, 1), o);
+            conv(convs_.at("decoder.N_conv"), curves.rows(1, 1), xcat0.rows(513, 1), o);
+        }
+        T catA = F1(1090), catB = F1(1090);
+        float* wa = A.f((size_t)B * 1024 * F1p);
+        float* wb = A.f((size_t)B * 1024 * F1p);
+        adain_resblk("decoder.encode", xcat0, catA.rows(0, 1024), false, wa, wb, nullptr);
+        tap("dec.encode", catA.rows(0, 1024));
+        conv(convs_.at("decoder.asr_res"), xcat0.rows(0, 512), catA.rows(1024, 64), ConvOpts{});
+        if (!dry_) {
+            launch_copy_rows(xcat0.rows(512, 2).p, xcat0.bs, xcat0.ld, catA.rows(1088, 2).p, catA.bs, catA.ld, 2, LF1, B,
+                             Fmax, stream_);
+            launch_copy_rows(catA.rows(1024, 66).p, catA.bs, catA.ld, catB.rows(1024, 66).p, catB.bs, catB.ld, 66, LF1,
+                             B, Fmax, stream_);
+        }
+        T* ci = &catA;
+        T* co = &catB;
+        for (int i = 0; i < 3; ++i) {
+            adain_resblk("decoder.decode." + std::to_string(i), *ci, co->rows(0, 1024), false, wa, wb, nullptr);
+            tap(("dec.decode." + std::to_string(i)).c_str(), co->rows(0, 1024));
+            std::swap(ci, co);
+        }
+        T g0 = F2(512);
+        {
+            float* ua = A.f((size_t)B * 512 * F2p);
+            float* ub = A.f((size_t)B * 512 * F2p);
+            float* uc = A.f((size_t)B * 1090 * F2p);
+            adain_resblk("decoder.decode.3", *ci, g0, true, ua, ub, uc);
+        }
+        tap("dec.decode.3", g0);
+        // --- Generator: harmonic source -> STFT -> 2 up-sampling stages -> iSTFT head ---
+        const std::string G = "decoder.generator.";
+        const long hs_ld = (long)600 * Fmax;
+        float* har_src = A.f((size_t)B * hs_ld);
+        float* phase = A.f((size_t)B * 9 * 2 * Fmax);
+        if (!dry_)
+            launch_source(curves.p, curves.bs, dF_, B, Fmax, wt(G + "m_source.l_linear.weight"),
+                          wt(G + "m_source.l_linear.bias"), seed, utt_base, noise_off, phase, har_src, hs_ld, stream_);
+        if (taps_on_ && !dry_) {
+            T hs;
+            hs.p = har_src; hs.bs = hs_ld; hs.ld = (int)hs_ld; hs.C = 1; hs.len = LenMap{dF_, 600, 0}; hs.Lmax = 600 * Fmax;
+            tap("gen.har_source", hs);
+        }
+        T har = F121(22);
+        if (!dry_) launch_stft(har_src, hs_ld, har.p, har.bs, har.ld, dF_, B, Fmax, stream_);
+        tap("gen.har", har);
+        T x = g0;
+        for (int st = 0; st < 2; ++st) {
+            const int ch = st == 0 ? 256 : 128;
+            auto S = [&](int C) { return st == 0 ? F20(C) : F121(C); };
+            T ns = S(ch), xj = S(ch), t1 = S(ch), xu = S(ch), xs = S(ch);
+            {
+                ConvOpts o;
+                if (st == 0) { o.stride = 6; o.pad = 3; }
+                conv(convs_.at(G + "noise_convs." + std::to_string(st)), har, ns, o);
+            }
+            adain_resblock1(G + "noise_res." + std::to_string(st), st == 0 ? 7 : 11, ns, ns, t1, ns, 0, 1.f);
+            tap(("gen.x_source." + std::to_string(st)).c_str(), ns);
+            {
+                ConvOpts o;  // x = ups(leaky_relu(x, 0.1)) (+ reflection pad on the last stage) + x_source
+                o.act = ACT_LEAKY; o.slope = 0.1f; o.pad = 1;
+                o.store = ST_UPSCATTER;
+                o.up_pad = st == 0 ? 5 : 3;
+                o.up_off = st == 0 ? 0 : 1;
+                o.up_reflect = st == 0 ? 0 : 1;
+                o.up_len = st == 0 ? LF20 : LF120;
+                o.resid = &ns;
+                conv(convs_.at(G + "ups." + std::to_string(st)), x, xu, o);
+            }
+            tap(("gen.ups." + std::to_string(st)).c_str(), xu);
+            static const int ks[3] = {3, 7, 11};
+            for (int j = 0; j < 3; ++j)
+                adain_resblock1(G + "resblocks." + std::to_string(st * 3 + j), ks[j], xu, xj, t1, xs, j > 0 ? 1 : 0,
+                                j == 2 ? 3.0f : 1.0f);
+            tap(("gen.stage." + std::to_string(st)).c_str(), xs);
+            x = xs;
+        }
+        T cp = F121(22);
+        {
+            ConvOpts o;
+            o.act = ACT_LEAKY; o.slope = 0.01f; o.pad = 3;
+            conv(convs_.at(G + "conv_post"), x, cp, o);
+        }
+        tap("gen.conv_post", cp);
+        float* spec = A.f((size_t)B * 22 * F120p);
+        if (!dry_) launch_istft_head(cp.p, cp.bs, cp.ld, spec, d_audio, audio_ld, dF_, B, Fmax, stream_);
+        if (taps_on_ && !dry_) {
+            T au;
+            au.p = d_audio; au.bs = audio_ld; au.ld = (int)audio_ld; au.C = 1; au.len = LenMap{dF_, 600, 0}; au.Lmax = 600 * Fmax;
+            tap("audio", au);
+        }
+    };
+    dry_ = true;
+    arenaF_.measure = true;
+    try {
+        back(arenaF_);
+    } catch (...) {
+        dry_ = false;
+        arenaF_.measure = false;
+        throw;
+    }
+    dry_ = false;
+    arenaF_.measure = false;
+    const size_t needF = arenaF_.off;
+    ensure_arena(arenaF_, needF);
+    back(arenaF_);
+}
+
+void Model::infer_host(const int64_t* ids, int64_t t_stride, const int32_t* lens, int B, const float* styles,
+                       const float* speeds, int n_speed, uint64_t seed, uint32_t flags, float** out,
+                       int64_t* out_lens) {
+    KX_REQUIRE(out && out_lens, "infer: null output argument");
+    *out = nullptr;
+    KX_REQUIRE(B >= 1, "infer: empty batch");
+    KX_REQUIRE(ids && lens && styles && speeds, "infer: null argument");
+    for (int b = 0; b < B; ++b) {
+        KX_REQUIRE(lens[b] >= 1 && lens[b] <= 512 && lens[b] <= t_stride, "infer: token count must be 1..512");
+        for (int t = 0; t < lens[b]; ++t) {
+            const int64_t id = ids[b * t_stride + t];
+            KX_REQUIRE(id >= 0 && id < 178, "infer: token id outside 0..177");
+        }
+    }
+    KX_HIP(hipSetDevice(device));
+    // I/O staging lives in its own arena: ids, styles, frames, audio
+    int64_t* d_ids;
+    float* d_styles;
+    int* d_fr;
+    auto planIO = [&](Arena& A, size_t audio_floats) {
+        A.off = 0;
+        d_ids = static_cast<int64_t*>(A.alloc((size_t)B * t_stride * 8));
+        d_styles = A.f((size_t)B * 256);
+        d_fr = A.i(B);
+        return A.f(audio_floats);
+    };
+    // worst case length is 50 frames per token; start from a typical 8 and retry once if short
+    int Tmax = 0;
+    for (int b = 0; b < B; ++b) Tmax = lens[b] > Tmax ? lens[b] : Tmax;
+    int64_t ld = (int64_t)600 * Tmax * 8;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        arenaIO_.measure = true;
+        planIO(arenaIO_, (size_t)B * ld);
+        const size_t need = arenaIO_.off;
+        arenaIO_.measure = false;
+        ensure_arena(arenaIO_, need);
+        float* d_audio = planIO(arenaIO_, (size_t)B * ld);
+        KX_HIP(hipMemcpyAsync(d_ids, ids, (size_t)B * t_stride * 8, hipMemcpyHostToDevice, stream_));
+        KX_HIP(hipMemcpyAsync(d_styles, styles, (size_t)B * 256 * 4, hipMemcpyHostToDevice, stream_));
+        int64_t need_ld = 0;
+        try {
+            infer_device(d_ids, t_stride, lens, B, d_styles, speeds, n_speed, seed, flags, d_audio, ld, d_fr, &need_ld);
+        } catch (const Error& e) {
+            if (attempt == 0 && need_ld > ld) {
+                ld = need_ld;
+                continue;
+            }
+            throw;
+        }
+        KX_HIP(hipStreamSynchronize(stream_));
+        int64_t total = 0;
+        for (int b = 0; b < B; ++b) {
+            out_lens[b] = (int64_t)600 * hF_[b];
+            total += out_lens[b];
+        }
+        float* host = static_cast<float*>(malloc((size_t)(total > 0 ? total : 1) * sizeof(float)));
+        if (!host) throw Error(3, "infer: out of host memory");
+        int64_t o = 0;
+        for (int b = 0; b < B; ++b) {
+            hipError_t e = hipMemcpy(host + o, d_audio + (int64_t)b * ld, (size_t)out_lens[b] * 4, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) {
+                free(host);
+                throw Error(3, std::string("infer: D2H copy failed: ") + hipGetErrorString(e));
+            }
+            o += out_lens[b];
+        }
+        *out = host;
+        return;
+    }
+}
+
+}  // namespace kx

@@ -1,0 +1,273 @@
+"""Host-side mirror of the reference's `OrtKoko` over the kokorox_hip C ABI (ctypes).
+
+Reference interface being mirrored (/root/reference/kokorox/src/onn/ort_koko.rs):
+    OrtKoko::new(model_path: String) -> Result<Self, String>                      (l.31-35)
+    OrtKoko::infer(&self, tokens: Vec<Vec<i64>>, styles: Vec<Vec<f32>>, speed: f32)
+        -> Result<ArrayBase<OwnedRepr<f32>, IxDyn>, Box<dyn Error>>               (l.37-91)
+`HipKoko.new` / `HipKoko.infer` keep the names, argument meaning and error behaviour
+(load failure and infer failure raise; an empty token list is an error instead of the
+reference's index panic at l.56).  There is NO CPU fallback: if libkokorox_hip.so is
+missing or no gfx950 device is visible, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkokorox_hip.so")
+
+KX_FLAG_NOISE_OFF = 1
+KX_FLAG_TAPS = 2
+STYLE_DIM = 256
+SAMPLES_PER_FRAME = 600
+
+_lib = None
+
+
+class KokoroxHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"kokorox_hip error {code}: {msg}")
+        self.code = code
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen libkokorox_hip.so (built by kokorox_amd.build / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise FileNotFoundError(
+            f"{p} is missing: build it with `python -m kokorox_amd.build` (hipcc, gfx950). "
+            "The HIP path has no CPU fallback.")
+    lib = C.CDLL(p)
+    vp, i32, i64, u32, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
+    cp, sz = C.c_char_p, C.c_size_t
+    sig = {
+        "kx_version": (cp, []),
+        "kx_init": (i32, [i32, cp, sz]),
+        "kx_create": (vp, [cp, i32, cp, sz]),
+        "kx_create_from_device_blob": (vp, [vp, sz, i32, cp, sz]),
+        "kx_destroy": (None, [vp]),
+        "kx_last_error": (cp, [vp]),
+        "kx_infer": (i32, [vp, vp, i64, vp, i32, vp, vp, i32, u64, u32, C.POINTER(C.POINTER(f32)), vp]),
+        "kx_free_audio": (None, [C.POINTER(f32)]),
+        "kx_infer_device": (i32, [vp, vp, i64, vp, i32, vp, vp, i32, u64, u32, vp, i64, vp, C.POINTER(i64)]),
+        "kx_sync": (i32, [vp]),
+        "kx_set_pinned_durations": (i32, [vp, vp, i32]),
+        "kx_set_utterance_base": (i32, [vp, u64]),
+        "kx_profile_enable": (i32, [vp, i32]),
+        "kx_profile_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "kx_debug_tap": (i32, [vp, cp, i32, vp, i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+        "kx_test_conv1d": (i32, [i32, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp,
+                                 i32, cp, sz]),
+        "kx_test_lstm": (i32, [i32, vp, i32, i32, i32] + [vp] * 9 + [cp, sz]),
+        "kx_test_source": (i32, [i32, vp, i32, i32, vp, f32, u64, u64, i32, vp, cp, sz]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here = the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+ABI_SYMBOLS = [
+    "kx_version", "kx_init", "kx_create", "kx_create_from_device_blob", "kx_destroy", "kx_last_error", "kx_infer",
+    "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_set_utterance_base",
+    "kx_profile_enable", "kx_profile_read", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source",
+]
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a) -> Optional[np.ndarray]:
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+class HipKoko:
+    """MI355X-native stand-in for `OrtKoko` (one instance per GPU, calls serialised)."""
+
+    def __init__(self, model_path: str, device: int = 0, _handle=None):
+        self._lib = load_library()
+        self.device = device
+        if _handle is not None:
+            self._h = _handle
+            return
+        err = C.create_string_buffer(512)
+        h = self._lib.kx_create(os.fsencode(model_path), device, err, len(err))
+        if not h:
+            # reference: `.expect("Failed to create Kokoro TTS model")`, koko.rs:572
+            raise RuntimeError(f"Failed to create Kokoro TTS model: {err.value.decode()}")
+        self._h = h
+
+    # -- reference-shaped API -------------------------------------------------------------
+    @classmethod
+    def new(cls, model_path: str, device: int = 0) -> "HipKoko":
+        return cls(model_path, device)
+
+    @classmethod
+    def from_device_blob(cls, data_ptr: int, n_bytes: int, device: int = 0) -> "HipKoko":
+        """Build from a weight blob already in this GPU's memory (after the RCCL broadcast)."""
+        lib = load_library()
+        err = C.create_string_buffer(512)
+        h = lib.kx_create_from_device_blob(C.c_void_p(data_ptr), n_bytes, device, err, len(err))
+        if not h:
+            raise RuntimeError(f"Failed to create Kokoro TTS model: {err.value.decode()}")
+        return cls("", device, _handle=h)
+
+    def infer(self, tokens: Sequence[Sequence[int]], styles: Sequence[Sequence[float]], speed: float,
+              seed: int = 0, flags: int = 0):
+        """tokens [[...]] (already 0-wrapped, koko.rs:1169-1175), styles [[256 floats]], speed.
+
+        Batch of one returns the waveform as a 1-D float32 array (what koko.rs:1179 flattens);
+        a batch of B returns a list of B arrays."""
+        if len(tokens) == 0 or len(tokens[0]) == 0:
+            raise ValueError("infer: empty token list")
+        if len(styles) != len(tokens):
+            raise ValueError("infer: one style row per utterance is required")
+        outs = self.infer_batch(tokens, styles, [float(speed)], seed=seed, flags=flags)
+        return outs[0] if len(outs) == 1 else outs
+
+    # -- batched / instrumented forms -------------------------------------------------------
+    def infer_batch(self, tokens, styles, speeds, seed: int = 0, flags: int = 0) -> List[np.ndarray]:
+        B = len(tokens)
+        lens = np.array([len(t) for t in tokens], dtype=np.int32)
+        stride = int(lens.max()) if B else 0
+        ids = np.zeros((B, max(stride, 1)), dtype=np.int64)
+        for b, t in enumerate(tokens):
+            ids[b, : len(t)] = np.asarray(t, dtype=np.int64)
+        st = _f32(np.asarray(styles, dtype=np.float32).reshape(B, -1))
+        if B and st.shape[1] != STYLE_DIM:
+            raise ValueError(f"infer: style rows must have {STYLE_DIM} floats")
+        sp = _f32(np.asarray(speeds, dtype=np.float32).reshape(-1))
+        out = C.POINTER(C.c_float)()
+        out_lens = np.zeros(max(B, 1), dtype=np.int64)
+        rc = self._lib.kx_infer(self._h, _ptr(ids), ids.shape[1], _ptr(lens), B, _ptr(st), _ptr(sp), sp.shape[0],
+                                seed, flags, C.byref(out), _ptr(out_lens))
+        self._check(rc)
+        try:
+            total = int(out_lens[:B].sum())
+            flat = np.ctypeslib.as_array(out, shape=(max(total, 1),))[:total].copy()
+        finally:
+            self._lib.kx_free_audio(out)
+        res, o = [], 0
+        for b in range(B):
+            res.append(flat[o: o + int(out_lens[b])])
+            o += int(out_lens[b])
+        return res
+
+    def infer_device(self, d_ids: int, t_stride: int, lens_host: np.ndarray, d_styles: int, speeds_host: np.ndarray,
+                     d_audio: int, audio_ld: int, d_frames: int, seed: int = 0, flags: int = 0) -> int:
+        """Raw device-pointer form (bench.py); returns the audio row length that is needed."""
+        lens_host = np.ascontiguousarray(lens_host, dtype=np.int32)
+        speeds_host = _f32(speeds_host)
+        need = C.c_int64(0)
+        rc = self._lib.kx_infer_device(self._h, C.c_void_p(d_ids), t_stride, _ptr(lens_host), lens_host.shape[0],
+                                       C.c_void_p(d_styles), _ptr(speeds_host), speeds_host.shape[0], seed, flags,
+                                       C.c_void_p(d_audio), audio_ld, C.c_void_p(d_frames), C.byref(need))
+        if rc != 0 and need.value > audio_ld:
+            return int(need.value)
+        self._check(rc)
+        return int(need.value)
+
+    def sync(self):
+        self._check(self._lib.kx_sync(self._h))
+
+    def set_pinned_durations(self, pattern: Optional[Sequence[int]]):
+        if not pattern:
+            self._check(self._lib.kx_set_pinned_durations(self._h, None, 0))
+            return
+        p = np.ascontiguousarray(pattern, dtype=np.int32)
+        self._check(self._lib.kx_set_pinned_durations(self._h, _ptr(p), p.shape[0]))
+
+    def set_utterance_base(self, base: int):
+        self._check(self._lib.kx_set_utterance_base(self._h, base))
+
+    def profile_enable(self, on: bool):
+        self._check(self._lib.kx_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        n, ms, fl = C.c_int64(0), C.c_double(0), C.c_double(0)
+        self._check(self._lib.kx_profile_read(self._h, C.byref(n), C.byref(ms), C.byref(fl)))
+        return int(n.value), float(ms.value), float(fl.value)
+
+    def tap(self, name: str, b: int = 0) -> np.ndarray:
+        c, l = C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.kx_debug_tap(self._h, name.encode(), b, None, 0, C.byref(c), C.byref(l)))
+        out = np.empty((c.value, l.value), dtype=np.float32)
+        self._check(self._lib.kx_debug_tap(self._h, name.encode(), b, _ptr(out), out.size, C.byref(c), C.byref(l)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.kx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise KokoroxHipError(rc, self._lib.kx_last_error(self._h).decode())
+
+
+# ---- stand-alone kernel hooks (tests) -----------------------------------------------------
+def _err_call(fn, *args):
+    err = C.create_string_buffer(512)
+    rc = fn(*args, err, len(err))
+    if rc != 0:
+        raise KokoroxHipError(rc, err.value.decode())
+
+
+def conv1d(x, w, bias=None, stride=1, pad=0, dil=1, transposed=False, act=0, slope=0.0, alpha=None, norm=None,
+           device=0):
+    """Run the MFMA conv kernel alone: x [B,Cin,L], w [Cout,Cin,k] ([Cin,Cout,k] if transposed)."""
+    lib = load_library()
+    x, w = _f32(x), _f32(w)
+    B, Cin, L = x.shape
+    k = w.shape[2]
+    if transposed:
+        Cout = w.shape[1]
+        Lout = (L - 1) * stride - 2 * pad + k
+    else:
+        Cout = w.shape[0]
+        Lout = (L + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    y = np.zeros((B, Cout, Lout), dtype=np.float32)
+    bias, alpha, norm = _f32(bias), _f32(alpha), _f32(norm)
+    _err_call(lib.kx_test_conv1d, device, _ptr(x), B, Cin, L, _ptr(w), _ptr(bias), Cout, k, stride, pad, dil,
+              1 if transposed else 0, act, float(slope), _ptr(alpha), _ptr(norm), _ptr(y), Lout)
+    return y
+
+
+def lstm(x, params, device=0):
+    """x [B,L,n_in]; params = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r) -> [B,L,512]."""
+    lib = load_library()
+    x = _f32(x)
+    B, L, n_in = x.shape
+    ps = [_f32(p) for p in params]
+    y = np.zeros((B, L, 512), dtype=np.float32)
+    _err_call(lib.kx_test_lstm, device, _ptr(x), B, L, n_in, *[_ptr(p) for p in ps], _ptr(y))
+    return y
+
+
+def harmonic_source(f0, lin_w, lin_b, seed=0, utt_base=0, noise_off=False, device=0):
+    """f0 [B,2F] -> har_source [B,600F]."""
+    lib = load_library()
+    f0 = _f32(f0)
+    B, F2 = f0.shape
+    lin_w = _f32(np.asarray(lin_w).reshape(-1))
+    out = np.zeros((B, 300 * F2), dtype=np.float32)
+    _err_call(lib.kx_test_source, device, _ptr(f0), B, F2, _ptr(lin_w), float(lin_b), seed, utt_base,
+              1 if noise_off else 0, _ptr(out))
+    return out
