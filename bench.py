@@ -1,0 +1,269 @@
+"""Headline benchmark: real-time factor of the Kokoro-82M forward at batch 64 per GPU.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (`OrtKoko::infer`'s replacement) over one batch of 64
+synthetic 128-phoneme utterances per GPU (BASELINE.json configs[2]), inputs
+already resident in HBM, durations pinned to 3,3,3,4 (F = 422 frames = 10.55 s of audio each).
+Ranks hold different utterances (weak scaling); the only collective is the one-time
+broadcast of the weight blob.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+_T0 = time.perf_counter()
+
+
+def progress(msg: str):
+    """Timestamped progress on stderr (a silent run is taken for a hang by the GPU runner)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def synthetic_ids(B: int, n_phonemes: int, seed: int) -> np.ndarray:
+    """ids uniform on 1..177, wrapped with id 0 at both ends (koko.rs:1169-1173)."""
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(1, 178, size=(B, n_phonemes), dtype=np.int64)
+    z = np.zeros((B, 1), np.int64)
+    return np.concatenate([z, ids, z], axis=1)
+
+
+def usable_cores() -> int:
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.999)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, (q + per - 1) // per))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
+def cpu_baseline(blob_path: str, n_utts: int, n_phonemes: int, pinned):
+    """The CPU restatement (oracle/, torch fp32 on the host cores) on a bounded sample."""
+    import torch
+    from kokorox_amd import weights as W
+    from oracle import kokoro_ref as R
+
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    progress(f"cpu baseline: {cores} threads, loading oracle")
+    o = R.KokoroOracle(blob_path)
+    ids = synthetic_ids(n_utts + 1, n_phonemes, seed=0)
+    voices = W.synthetic_voices(2)
+    style = voices[0, n_phonemes, 0]
+    o.forward(ids[0][:34], style, 1.0, seed=2, utt=0, pinned_dur=pinned[:34])  # warm-up (short)
+    t = time.perf_counter()
+    audio_s = 0.0
+    for i in range(n_utts):
+        a, _ = o.forward(ids[i + 1], style, 1.0, seed=2, utt=i, pinned_dur=pinned)
+        audio_s += a.shape[0] / 24000.0
+        progress(f"cpu baseline: utterance {i + 1}/{n_utts} done at {time.perf_counter() - t:.1f} s")
+    wall = time.perf_counter() - t
+    return {"value": audio_s / wall, "unit": "x realtime (audio-s/wall-s)", "cores": cores, "kind": "port",
+            "sample": f"{n_utts} of the same 128-phoneme utterances, sequential batch-1 like the reference's "
+                      f"Mutex<Session>, torch-CPU fp32 restatement (not ONNX Runtime), {wall:.1f} s wall",
+            "utt_per_s": n_utts / wall}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--phonemes", type=int, default=128)
+    ap.add_argument("--cpu-utts", type=int, default=3, help="utterances in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--free-run", type=int, default=1, help="also time one step with predicted durations")
+    a = ap.parse_args()
+
+    import faulthandler
+    faulthandler.dump_traceback_later(300, repeat=True, file=sys.stderr)
+    import torch
+    import torch.distributed as dist
+    from kokorox_amd import dist as kd
+    from kokorox_amd import hip_koko as hk
+    from kokorox_amd import weights as W
+
+    rank, local_rank, world = kd.env_rank_world()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- weights: rank 0 owns the file, everyone else gets it over RCCL/xGMI once ----------
+    progress("preparing synthetic weight blob")
+    blob_path = W.ensure_synthetic_blob() if rank == 0 else ""
+    t0 = time.perf_counter()
+    blob = kd.broadcast_blob(blob_path, dev, rank, world)
+    torch.cuda.synchronize()
+    t_bcast = time.perf_counter() - t0
+    progress(f"blob on device ({t_bcast:.2f} s); building model")
+    model = hk.HipKoko.from_device_blob(blob.data_ptr(), blob.numel(), device=local_rank)
+    del blob
+    progress("model ready")
+
+    # ---- this rank's utterances, resident in HBM -------------------------------------------
+    B, T = a.batch, a.phonemes + 2
+    ids = torch.from_numpy(synthetic_ids(B, a.phonemes, seed=1000 + rank)).to(dev)
+    voices = W.synthetic_voices(4)
+    styles = torch.from_numpy(np.stack([voices[(rank * B + b) % 4, a.phonemes, 0] for b in range(B)])).to(dev)
+    lens = np.full(B, T, dtype=np.int32)
+    speeds = np.ones(1, dtype=np.float32)
+    pinned = np.array([3, 3, 3, 4] * ((T + 3) // 4), dtype=np.int64)[:T]
+    F = int(pinned.sum())
+    audio_ld = 600 * F
+    audio = torch.empty((B, audio_ld), dtype=torch.float32, device=dev)
+    frames = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    model.set_utterance_base(rank * B)
+    model.set_pinned_durations([3, 3, 3, 4])
+
+    def step():
+        need = model.infer_device(ids.data_ptr(), T, lens, styles.data_ptr(), speeds, audio.data_ptr(), audio_ld,
+                                  frames.data_ptr(), seed=2)
+        assert need <= audio_ld, (need, audio_ld)
+
+    def fence():
+        model.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step()
+        model.sync()
+        progress(f"warmup step {i + 1}/{a.warmup} done")
+    fence()
+    model.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    wall = time.perf_counter() - t0
+    progress(f"{a.steps} timed steps: {wall:.3f} s")
+    n_launch, conv_ms, conv_flops = model.profile_read()
+    model.profile_enable(False)
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    wall = float(wall_t.item())
+
+    fr = frames.cpu().numpy()
+    assert (fr == F).all(), fr
+    a_host = audio[:, : 600 * F].float()
+    finite = bool(torch.isfinite(a_host).all().item())
+    audio_s_per_step = world * B * F * 600 / 24000.0
+    rtf = audio_s_per_step * a.steps / wall
+    utt_s = world * B * a.steps / wall
+
+    free = None
+    if a.free_run:
+        model.set_pinned_durations(None)
+        cap = 600 * 50 * 4  # generous row: retried below if the prediction is longer
+        buf = torch.empty((B, cap), dtype=torch.float32, device=dev)
+        need = model.infer_device(ids.data_ptr(), T, lens, styles.data_ptr(), speeds, buf.data_ptr(), cap,
+                                  frames.data_ptr(), seed=2)
+        if need > cap:
+            cap = need
+            buf = torch.empty((B, cap), dtype=torch.float32, device=dev)
+        # untimed pass so that the arenas have grown to this shape before the timed one
+        model.infer_device(ids.data_ptr(), T, lens, styles.data_ptr(), speeds, buf.data_ptr(), cap,
+                           frames.data_ptr(), seed=2)
+        fence()
+        t1 = time.perf_counter()
+        model.infer_device(ids.data_ptr(), T, lens, styles.data_ptr(), speeds, buf.data_ptr(), cap,
+                           frames.data_ptr(), seed=2)
+        fence()
+        w1 = time.perf_counter() - t1
+        sf = int(frames.cpu().numpy().sum())
+        progress(f"free-running step: {w1:.3f} s, sum frames {sf}")
+        free = {"sum_frames_rank0": sf, "audio_s_rank0": sf * 600 / 24000.0, "wall_s": w1,
+                "rtf_rank0": sf * 600 / 24000.0 / w1}
+        del buf
+
+    if rank == 0:
+        flops_per_utt = (0.1635 * T + 1.317 * F) * 1e9  # SURVEY.md §8d model
+        out = {
+            "metric": "real-time factor (audio-s/wall-s), 24 kHz, batch=64",
+            "value": rtf,
+            "unit": "x realtime",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": wall / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (seeded random-init Kokoro-82M weights, uniform phoneme ids, N(0,0.1) voice rows)",
+            "config": {
+                "workload": f"batch={B}/GPU synthetic {a.phonemes}-phoneme utterances (T={T}), durations pinned "
+                            f"3,3,3,4 -> F={F} frames = {F * 600 / 24000.0:.2f} s each, noise on, inputs in HBM",
+                "batch_per_gpu": B, "tokens": T, "frames": F, "parallelism": f"utterance-sharded x{world}, "
+                "one-time weight broadcast",
+            },
+            "utterances_per_s": utt_s,
+            "audio_s_per_step": audio_s_per_step,
+            "finite": finite,
+            "weight_broadcast_s": t_bcast,
+            "model_tflops": flops_per_utt * world * B * a.steps / wall / 1e12,
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "kx::conv1d_mfma_kernel<128,128,2,2> (f32 32x32x2 MFMA implicit GEMM)",
+                "achieved": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": (conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if conv_ms > 0 else None,
+                "traffic": None,
+                "launches_per_step": n_launch / max(a.steps, 1),
+                "avg_launch_ms": conv_ms / max(n_launch, 1),
+                "gflop_per_launch": conv_flops / max(n_launch, 1) / 1e9,
+                "kernel_share_of_wall": conv_ms * 1e-3 / wall,
+            },
+            "free_running": free,
+        }
+        if world == 1 and a.cpu_utts > 0:
+            out["cpu_baseline"] = cpu_baseline(blob_path, a.cpu_utts, a.phonemes, pinned)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    model.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -108,7 +108,8 @@ int kx_set_pinned_durations(kx_model* m, const int32_t* pattern, int n);
 int kx_set_utterance_base(kx_model* m, uint64_t utt_base);
 
 /* Per-kernel-class HIP-event timing on the model's stream (bench.py roofline leg).
- * While enabled every launch of the conv1d MFMA kernel is bracketed by events.
+ * While enabled every launch of the dominant kernel, conv1d_mfma_kernel<128,128,2,2>, is
+ * bracketed by events on the model's stream.
  * kx_profile_read drains them: launches, summed milliseconds and summed algorithmic
  * FLOPs (2*Cout*Cin*k*columns per launch) since the last read. */
 int kx_profile_enable(kx_model* m, int on);

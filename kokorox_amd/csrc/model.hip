@@ -352,7 +352,7 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     a.up_reflect = o.up_reflect;
     a.up_cout = w.up_cout ? w.up_cout : 1;
     const int max_cols = (o.store == ST_UPSCATTER) ? in.Lmax + 1 : out.Lmax;
-    if (prof_on_) {
+    if (prof_on_ && w.BM == 128) {  // the dominant instantiation conv1d_mfma_kernel<128,128,2,2>
         const LenMap& lm = (o.store == ST_UPSCATTER) ? in.len : out.len;
         const std::vector<int>& hl = (lm.lens == dT_) ? hT_ : hF_;
         double cols = 0;

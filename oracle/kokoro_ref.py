@@ -300,11 +300,16 @@ class KokoroOracle:
             env[n: n + 5 * nf: 5] += self.win_sq[n]
         return (out / env)[10: 10 + 5 * (nf - 1)]
 
-    def generator(self, x, s, f0_curve, seed, utt, noise_scale, taps):
+    def generator(self, x, s, f0_curve, seed, utt, noise_scale, taps, har_override=None):
         g = "decoder.generator"
         w = self.w
         har_src = self.source(f0_curve, seed, utt, noise_scale, taps)
         har = self.stft(har_src)[None]
+        if har_override is not None:
+            # second teacher-forced edge: atan2's branch cut.  Where re < 0 and |im| is at rounding level
+            # the phase is +pi or -pi by the sign of a 1e-8 number; tests compare the STFT modulo 2*pi
+            # and pin it before comparing what follows (DESIGN.md "Parity").
+            har = torch.as_tensor(np.asarray(har_override, dtype=np.float32)).to(self.dt)[None]
         taps["gen.har"] = har[0]
         for i in range(2):
             x = F.leaky_relu(x, 0.1)
@@ -330,7 +335,7 @@ class KokoroOracle:
         ph = torch.sin(x[0, 11:])
         return self.istft(mag, ph)
 
-    def decoder(self, asr, f0_curve, n_curve, s, seed, utt, noise_scale, taps):
+    def decoder(self, asr, f0_curve, n_curve, s, seed, utt, noise_scale, taps, har_override=None):
         """Decoder.forward (istftnet.py): asr [512,F], curves [2F], s [1,128]."""
         w = self.w
         f0 = F.conv1d(f0_curve[None, None], w["decoder.F0_conv.weight"], w["decoder.F0_conv.bias"],
@@ -345,12 +350,12 @@ class KokoroOracle:
             x = torch.cat([x, asr_res, f0, n], dim=1)
             x = self._adain_resblk(x, s, f"decoder.decode.{i}", upsample=(i == 3))
             taps[f"dec.decode.{i}"] = x[0]
-        return self.generator(x, s, f0_curve, seed, utt, noise_scale, taps)
+        return self.generator(x, s, f0_curve, seed, utt, noise_scale, taps, har_override)
 
     # -- whole path (KModel.forward_with_tokens, model.py) ------------------------------
     @torch.no_grad()
     def forward(self, input_ids, style, speed=1.0, seed=0, utt=0, noise_scale=1.0,
-                pinned_dur=None, taps=None, f0_override=None, n_override=None):
+                pinned_dur=None, taps=None, f0_override=None, n_override=None, har_override=None):
         """input_ids [T] (0-padded both ends, koko.rs:1169-1173), style [256] -> waveform.
 
         Returns (waveform float tensor [600*F], pred_dur int64 [T])."""
@@ -395,7 +400,8 @@ class KokoroOracle:
         t_en = self.text_encoder(ids, taps)
         taps["text_enc.out"] = t_en
         asr = t_en[:, idx]
-        audio = self.decoder(asr, curves[0], curves[1], style[None, :128], seed, utt, noise_scale, taps)
+        audio = self.decoder(asr, curves[0], curves[1], style[None, :128], seed, utt, noise_scale, taps,
+                             har_override)
         taps["audio"] = audio[None]
         return audio, pred_dur
 

@@ -1,0 +1,109 @@
+"""GPU: each hand-written kernel, alone, through the C ABI test hooks, against torch CPU in float64.
+
+Tolerances: f32 MFMA accumulation is a k-ordered fmaf chain (cdna_hip_programming.md §3), so the
+error bound is ~1e-7 * sum|a*b|; 2e-5 absolute on O(1) outputs with K up to 3270 leaves >5x margin.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CONV_CASES = [
+    # B, Cin, Cout, L, k, stride, pad, dil
+    (2, 16, 32, 70, 3, 1, 1, 1),
+    (1, 24, 130, 300, 7, 1, 9, 3),        # Cin/Cout not multiples of the tile, dilation 3
+    (2, 128, 128, 517, 11, 1, 25, 5),     # generator stage-1 shape, dilation 5
+    (1, 256, 256, 261, 7, 1, 3, 1),       # generator stage-0 shape
+    (1, 22, 256, 601, 12, 6, 3, 1),       # noise_convs[0]: stride 6
+    (2, 1, 1, 40, 3, 2, 1, 1),            # F0_conv: 1 channel, stride 2
+    (1, 640, 50, 33, 1, 1, 0, 1),         # duration projection as k=1 conv
+    (1, 1090, 64, 45, 3, 1, 1, 1),        # decoder concat width
+    (1, 128, 22, 700, 7, 1, 3, 1),        # conv_post (BM=32 tile)
+    (3, 8, 8, 1, 1, 1, 0, 1),             # single column
+    (1, 5, 7, 130, 5, 1, 2, 1),           # ragged channel counts, text-encoder kernel
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,L,k,s,p,d", CONV_CASES)
+def test_conv1d_mfma(B, Cin, Cout, L, k, s, p, d):
+    from kokorox_amd import hip_koko as hk
+    rng = np.random.default_rng(B * 1000 + Cin + L)
+    x = rng.standard_normal((B, Cin, L), dtype=np.float32)
+    w = (rng.standard_normal((Cout, Cin, k), dtype=np.float32) / np.sqrt(Cin * k)).astype(np.float32)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    y = hk.conv1d(x, w, b, stride=s, pad=p, dil=d)
+    ref = F.conv1d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                   stride=s, padding=p, dilation=d).numpy()
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() < 2e-5
+
+
+@pytest.mark.parametrize("act", [1, 2])
+def test_conv1d_fused_adain_activation(act):
+    """AdaIN affine + leaky / snake applied while staging the input tile; zero padding comes AFTER."""
+    from kokorox_amd import hip_koko as hk
+    rng = np.random.default_rng(act)
+    B, Cin, Cout, L, k = 2, 40, 48, 200, 7
+    x = rng.standard_normal((B, Cin, L), dtype=np.float32)
+    w = (rng.standard_normal((Cout, Cin, k), dtype=np.float32) / np.sqrt(Cin * k)).astype(np.float32)
+    norm = rng.standard_normal((3, B, Cin), dtype=np.float32)
+    alpha = (rng.random(Cin, dtype=np.float32) + 0.5).astype(np.float32)
+    y = hk.conv1d(x, w, None, pad=3, act=act, slope=0.2, alpha=alpha, norm=norm)
+    n = torch.from_numpy(norm).double()
+    xt = (torch.from_numpy(x).double() - n[0][:, :, None]) * n[1][:, :, None] + n[2][:, :, None]
+    if act == 2:
+        a = torch.from_numpy(alpha).double()[None, :, None]
+        xt = xt + (1 / a) * torch.sin(a * xt) ** 2
+    else:
+        xt = F.leaky_relu(xt, 0.2)
+    ref = F.conv1d(xt, torch.from_numpy(w).double(), padding=3).numpy()
+    assert np.abs(y - ref).max() < 3e-5
+
+
+@pytest.mark.parametrize("Cin,Cout,L,s", [(16, 24, 37, 10), (256, 128, 50, 6), (512, 256, 21, 10), (8, 8, 1, 6)])
+def test_conv_transpose_polyphase(Cin, Cout, L, s):
+    from kokorox_amd import hip_koko as hk
+    rng = np.random.default_rng(Cin + L)
+    k = 2 * s
+    x = rng.standard_normal((2, Cin, L), dtype=np.float32)
+    w = (rng.standard_normal((Cin, Cout, k), dtype=np.float32) / np.sqrt(Cin * 2)).astype(np.float32)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    y = hk.conv1d(x, w, b, stride=s, pad=(k - s) // 2, transposed=True)
+    ref = F.conv_transpose1d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                             stride=s, padding=(k - s) // 2).numpy()
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() < 2e-5
+
+
+@pytest.mark.parametrize("L,n_in", [(19, 72), (1, 640), (130, 512)])
+def test_bilstm(L, n_in):
+    from kokorox_amd import hip_koko as hk
+    torch.manual_seed(L)
+    m = torch.nn.LSTM(n_in, 256, 1, batch_first=True, bidirectional=True).double()
+    x = torch.randn(2, L, n_in, dtype=torch.float64)
+    with torch.no_grad():
+        ref = m(x)[0].numpy()
+    ps = [getattr(m, n + suf).detach().float().numpy() for suf in ("", "_reverse")
+          for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")]
+    y = hk.lstm(x.float().numpy(), ps)
+    assert np.abs(y - ref).max() < 1e-5
+
+
+def test_harmonic_source_phase_is_bit_faithful(oracle):
+    """The ~1e5 rad phase path must reproduce torch-CPU float32 exactly; only sin/tanh/log ulps remain."""
+    from kokorox_amd import hip_koko as hk
+    rng = np.random.default_rng(3)
+    F2 = 120
+    f0 = (rng.standard_normal((3, F2)) * 150 + 110).astype(np.float32)
+    f0[2, :40] = 0.0  # an unvoiced stretch and negative values are both in range
+    lw = oracle.w["decoder.generator.m_source.l_linear.weight"].numpy()
+    lb = float(oracle.w["decoder.generator.m_source.l_linear.bias"][0])
+    y = hk.harmonic_source(f0, lw, lb, seed=7, utt_base=5)
+    for b in range(3):
+        ref = oracle.source(torch.from_numpy(f0[b]), 7, 5 + b, 1.0, {}).numpy()
+        assert np.abs(y[b] - ref).max() < 2e-6, b
+    y0 = hk.harmonic_source(f0[:1], lw, lb, seed=7, utt_base=5, noise_off=True)
+    ref0 = oracle.source(torch.from_numpy(f0[0]), 7, 5, 0.0, {}).numpy()
+    assert np.abs(y0[0] - ref0).max() < 2e-6

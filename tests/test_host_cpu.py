@@ -1,0 +1,120 @@
+"""CPU: host-side logic — weight container, caller-side input producers, C ABI surface, loud failure."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from kokorox_amd import voices as V
+from kokorox_amd import weights as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_param_count_and_spec():
+    spec = W.tensor_spec()
+    assert W.n_params() == 81_140_664  # model card 81.76 M minus the unused ALBERT pooler and weight-norm g's
+    assert len(spec) == len(set(spec))
+    assert spec["decoder.generator.ups.0.weight"][0] == (512, 256, 20)
+    assert spec["bert.embeddings.word_embeddings.weight"][0] == (178, 128)
+
+
+def test_blob_roundtrip(tmp_path):
+    from collections import OrderedDict
+    t = OrderedDict(a=np.arange(12, dtype=np.float32).reshape(3, 4), b=np.ones((5,), np.float32),
+                    c=np.zeros((2, 3, 4), np.float32))
+    p = str(tmp_path / "x.kxw")
+    W.write_blob(p, t)
+    r = W.read_blob(p)
+    assert list(r) == ["a", "b", "c"]
+    for k in t:
+        np.testing.assert_array_equal(np.asarray(r[k]), t[k])
+    with open(p, "r+b") as f:
+        f.write(b"BADMAGIC")
+    with pytest.raises(ValueError):
+        W.read_blob(p)
+
+
+def test_synthetic_weights_are_deterministic():
+    a = W._init(np.random.default_rng(5), (4, 3), ("fan_in", 1.0, 3))
+    b = W._init(np.random.default_rng(5), (4, 3), ("fan_in", 1.0, 3))
+    np.testing.assert_array_equal(a, b)
+    v = W.synthetic_voices(2)
+    assert v.shape == (2, 511, 1, 256) and not v[:, 510].any()
+
+
+def test_reference_token_rows(ref_inputs):
+    """Known-answer rows of the reference's own tokenizer tests (tokenize.rs:120-129)."""
+    sym = ref_inputs["symbols"]
+    assert len(sym) == 178
+    for text, ids in ref_inputs["token_rows"].items():
+        assert V.tokenize(text, sym) == ids
+    assert V.tokenize("Hi世!", sym) == V.tokenize("Hi!", sym)  # unknown chars are dropped
+    assert V.pad_tokens([5, 6], initial_silence=2) == [[0, 30, 30, 5, 6, 0]]
+    row = ref_inputs["ort_koko_sample_row"]
+    assert row[0] == 0 and row[-1] == 0 and max(row) < 178
+
+
+def test_mix_styles_matches_reference_rule(tmp_path):
+    rng = np.random.default_rng(0)
+    tab = {"af_sky": rng.standard_normal((510, 1, 256)).astype(np.float32),
+           "af_nicole": rng.standard_normal((510, 1, 256)).astype(np.float32)}
+    p = str(tmp_path / "voices.npz")
+    np.savez(p, **tab)
+    styles = V.load_voices(p)
+    assert styles["af_sky"].shape == (511, 1, 256) and not styles["af_sky"][510].any()  # hf_cache.rs:302-309
+    one = V.mix_styles(styles, "af_sky", 128)
+    np.testing.assert_array_equal(np.float32(one[0]), tab["af_sky"][128, 0])
+    mix = np.float32(V.mix_styles(styles, "af_sky.4+af_nicole.5", 17)[0])
+    want = (tab["af_sky"][17, 0] * np.float32(np.float32(4) * np.float32(0.1))
+            + tab["af_nicole"][17, 0] * np.float32(np.float32(5) * np.float32(0.1)))
+    np.testing.assert_allclose(mix, want, rtol=1e-6)       # un-normalised: weights sum to 0.9
+    # parts without '.' or with a non-numeric weight are skipped silently (koko.rs:1275-1285)
+    np.testing.assert_array_equal(np.float32(V.mix_styles(styles, "af_sky.4+junk+af_nicole.x", 3)[0]),
+                                  np.float32(V.mix_styles(styles, "af_sky.4+zzz", 3)[0]))
+    with pytest.raises(KeyError):
+        V.mix_styles(styles, "nobody", 3)
+    with pytest.raises(KeyError):
+        V.mix_styles(styles, "nobody.4+af_sky.5", 3)
+    with pytest.raises(ValueError):
+        V.mix_styles(styles, "a+b", 3)
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "kokorox_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(kx_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from kokorox_amd import hip_koko as hk
+    lib = hk.load_library()
+    names = _header_symbols()
+    assert "kx_infer" in names and "kx_create" in names and len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"libkokorox_hip.so does not export {n}"
+    assert sorted(hk.ABI_SYMBOLS) == names
+    assert b"gfx950" in lib.kx_version()
+
+
+def test_no_gpu_fails_loudly():
+    """The product path has no CPU fallback: without a device, init/create report an error."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from kokorox_amd import hip_koko as hk
+    lib = hk.load_library()
+    err = C.create_string_buffer(256)
+    assert lib.kx_init(0, err, len(err)) == 3 and b"no HIP device" in err.value
+    with pytest.raises(RuntimeError, match="Failed to create Kokoro TTS model"):
+        hk.HipKoko.new("/nonexistent.kxw")
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "kokorox_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f), encoding="utf-8").read()
+                assert "import oracle" not in src and "from oracle" not in src, f

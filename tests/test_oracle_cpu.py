@@ -1,0 +1,107 @@
+"""CPU: the oracle against its committed golden vectors, known-answer pieces and self-consistency."""
+import numpy as np
+import torch
+
+from kokorox_amd import weights as W
+from oracle import kokoro_ref as R
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors, philox4x32-10
+    kat = [
+        ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+        ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+        ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+         (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+    ]
+    for ctr, key, want in kat:
+        got = R.philox4x32_10(*[np.uint32(c) for c in ctr], key[0], key[1])
+        assert tuple(int(g) for g in got) == want
+
+
+def test_noise_stream_fixture_and_moments():
+    import os
+    from conftest import GOLD
+    with np.load(os.path.join(GOLD, "noise_stream.npz")) as z:
+        want = z["z"]
+    got = R.gauss_noise(0x1234567890ABCDEF, 3, 64)
+    np.testing.assert_array_equal(got, want)
+    big = R.gauss_noise(7, 0, 40000)
+    assert abs(float(big.mean())) < 0.01 and abs(float(big.std()) - 1.0) < 0.01
+    assert not np.array_equal(R.gauss_noise(7, 0, 16), R.gauss_noise(7, 1, 16))
+
+
+def test_oracle_matches_golden(oracle, golden):
+    for name, g in golden.items():
+        taps = {}
+        audio, dur = oracle.forward(g["ids"], g["style"], float(g["speed"]), seed=int(g["seed"]), utt=0, taps=taps)
+        np.testing.assert_array_equal(dur.numpy(), g["pred_dur"])
+        assert audio.shape[0] == 600 * int(g["pred_dur"].sum())
+        for k in g:
+            if k.startswith("tap:"):
+                ref = g[k]
+                got = taps[k[4:]].numpy()
+                scale = max(1.0, float(np.abs(ref).max()))
+                # same code, same machine class: only thread-count dependent summation order may differ;
+                # the waveform itself is compared with the F0 edge pinned (see DESIGN.md "Parity")
+                if k in ("tap:audio", "tap:gen.har_source"):
+                    continue
+                assert np.abs(got - ref).max() <= 2e-5 * scale, (name, k)
+        taps2 = {}
+        audio2, _ = oracle.forward(g["ids"], g["style"], float(g["speed"]), seed=int(g["seed"]), utt=0, taps=taps2,
+                                   f0_override=g["tap:pred.F0"][0], n_override=g["tap:pred.N"][0])
+        np.testing.assert_allclose(taps2["gen.har_source"].numpy(), g["tap:gen.har_source"], atol=2e-6)
+        assert np.abs(audio2.numpy() - g["tap:audio"][0]).max() < 1e-4
+
+
+def test_oracle_fp64_agrees_on_well_conditioned_stages(oracle, blob_path, golden):
+    """Everything up to the F0 curve agrees fp32 vs fp64; the waveform agrees once har_source is pinned."""
+    o64 = R.KokoroOracle(blob_path, torch.float64)
+    g = golden["hello_world"]
+    t32, t64 = {}, {}
+    a32, d32 = oracle.forward(g["ids"], g["style"], 1.0, seed=2, utt=0, taps=t32)
+    a64, d64 = o64.forward(g["ids"], g["style"], 1.0, seed=2, utt=0, taps=t64)
+    assert torch.equal(d32, d64)
+    for k in ("bert.out", "d_en", "dur_enc.2", "pred.N", "text_enc.out", "dec.decode.3"):
+        ref = t64[k].numpy()
+        assert np.abs(t32[k].numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), k
+    rel_f0 = np.abs(t32["pred.F0"].numpy() - t64["pred.F0"].numpy()).max() / np.abs(t64["pred.F0"].numpy()).max()
+    assert rel_f0 < 1e-4
+    har = t32["gen.har_source"][0].double()
+    o64.source = lambda *args, **kw: har
+    a64p, _ = o64.forward(g["ids"], g["style"], 1.0, seed=2, utt=0)
+    assert float((a32.double() - a64p).abs().max()) < 1e-4
+
+
+def test_stft_istft_roundtrip(oracle):
+    """Size-independent property of the analysis/synthesis pair: istft(stft(x)) == x."""
+    torch.manual_seed(0)
+    x = torch.randn(600 * 3)
+    s = oracle.stft(x)
+    y = oracle.istft(s[:11], s[11:])
+    assert y.shape == x.shape
+    assert float((x - y).abs().max()) < 1e-5
+
+
+def test_source_is_linear_free_of_random_phase(oracle):
+    """uv mask and amplitude bounds of the harmonic source; deterministic given (seed, utt)."""
+    f0 = torch.tensor([0.0, 5.0, 220.0, 220.0, 110.0, 0.0], dtype=torch.float32)
+    a = oracle.source(f0, 5, 0, 1.0, {})
+    b = oracle.source(f0, 5, 0, 1.0, {})
+    assert torch.equal(a, b) and a.shape[0] == 1800
+    assert float(a.abs().max()) <= 1.0
+
+
+def test_speed_scales_durations(oracle, golden):
+    g = golden["hello_world"]
+    _, d1 = oracle.forward(g["ids"], g["style"], 1.0, seed=2)
+    _, d2 = oracle.forward(g["ids"], g["style"], 2.0, seed=2)
+    assert int(d2.sum()) < int(d1.sum()) and int(d2.min()) >= 1
+
+
+def test_blob_readers_agree(blob_path):
+    a = W.read_blob(blob_path)
+    b = R.load_blob(blob_path)
+    assert list(a.keys()) == list(b.keys())
+    for k in ("bert_encoder.weight", "decoder.generator.ups.1.weight", "predictor.lstm.bias_hh_l0_reverse"):
+        np.testing.assert_array_equal(np.asarray(a[k]), b[k])

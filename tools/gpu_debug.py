@@ -135,6 +135,12 @@ def taps_report(log, oracle, blob, token_counts):
         n = m.tap("pred.N", b)[0]
         taps2 = {}
         audio2, _ = oracle.forward(ids_all[b], styles[b], 1.0, seed=2, utt=b, taps=taps2, f0_override=f0, n_override=n)
+        har_g = m.tap("gen.har", b)
+        taps3 = {}
+        oracle.forward(ids_all[b], styles[b], 1.0, seed=2, utt=b, taps=taps3, f0_override=f0, n_override=n, har_override=har_g)
+        for name in ("gen.x_source.0", "gen.stage.0", "gen.stage.1", "gen.conv_post", "audio"):
+            mx, rl = rel(m.tap(name, b), taps3[name].float().numpy())
+            log(f"   [F0+STFT pinned] {name:15s} max|d| {mx:.3e}  rel {rl:.3e}")
         for name in ("gen.har_source", "gen.har", "gen.x_source.0", "gen.ups.0", "gen.stage.0", "gen.x_source.1",
                      "gen.ups.1", "gen.stage.1", "gen.conv_post", "audio"):
             g = m.tap(name, b)
@@ -144,6 +150,16 @@ def taps_report(log, oracle, blob, token_counts):
                 continue
             mx, rl = rel(g, refn)
             log(f"   [F0 pinned] {name:15s} max|d| {mx:.3e}  rel {rl:.3e}")
+            if name == "gen.har" and mx > 1.0:
+                hs = torch.from_numpy(m.tap("gen.har_source", b)[0])
+                xp = torch.nn.functional.pad(hs[None, None], (10, 10), mode="replicate")
+                re = torch.nn.functional.conv1d(xp, oracle.fwd_re, stride=5)[0].numpy()
+                im = torch.nn.functional.conv1d(xp, oracle.fwd_im, stride=5)[0].numpy()
+                for (c, f) in np.argwhere(np.abs(g - refn) > 1.0)[:12]:
+                    k = c - 11
+                    log(f"      flip at bin {k} frame {f}/{g.shape[1]}: gpu {g[c, f]:+.6f} oracle {refn[c, f]:+.6f}  "
+                        f"cpu re {re[k, f]:+.3e} im {im[k, f]:+.3e} signbit(im) {bool(np.signbit(im[k, f]))}  "
+                        f"gpu mag {g[k, f]:.3e} window {hs[max(0, 5 * f - 10): 5 * f + 10].numpy().round(4).tolist()}")
     m.close()
 
 
