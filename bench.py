@@ -65,6 +65,23 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+def pmc_traffic(B, T, F):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/*pmc_conv_traffic.json, written by tools/summarize_pmc.py for this same workload);
+    None when no pass matches.  PMC passes cannot run inside this process."""
+    import glob
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_conv_traffic.json"))):
+        try:
+            d = json.load(open(p))
+        except Exception:
+            continue
+        w = d.get("workload", {})
+        if (w.get("batch"), w.get("tokens"), w.get("frames")) == (B, T, F):
+            best = d
+    return None if best is None else best["traffic_bytes_per_launch"]
+
+
 def cpu_baseline(blob_path: str, n_utts: int, n_phonemes: int, pinned):
     """The CPU restatement (oracle/, torch fp32 on the host cores) on a bounded sample."""
     import torch
@@ -100,6 +117,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--phonemes", type=int, default=128)
     ap.add_argument("--cpu-utts", type=int, default=3, help="utterances in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--detail", default="", help="write a per-shape table of the conv launches to this file")
     ap.add_argument("--free-run", type=int, default=1, help="also time one step with predicted durations")
     a = ap.parse_args()
 
@@ -174,6 +192,18 @@ def main():
     wall = time.perf_counter() - t0
     progress(f"{a.steps} timed steps: {wall:.3f} s")
     n_launch, conv_ms, conv_flops = model.profile_read()
+    if a.detail and rank == 0:
+        det = model.profile_detail()
+        per = len(det) // max(a.steps, 1)
+        agg = {}
+        for r in det[-per:]:
+            key = tuple(int(v) for v in r[:6])
+            t = agg.setdefault(key, [0, 0.0, 0.0])
+            t[0] += 1; t[1] += r[7]; t[2] += r[8]
+        with open(a.detail, "w") as f:
+            f.write("rows Cin taps dil stride store launches GFLOP ms TFLOP/s\n")
+            for key, (n, fl, ms) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+                f.write(" ".join(f"{v:5d}" for v in key) + f" {n:4d} {fl / 1e9:10.1f} {ms:9.3f} {fl / ms / 1e9:8.1f}\n")
     model.profile_enable(False)
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
     if world > 1:
@@ -246,7 +276,7 @@ def main():
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": (conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if conv_ms > 0 else None,
-                "traffic": None,
+                "traffic": pmc_traffic(B, T, F),
                 "launches_per_step": n_launch / max(a.steps, 1),
                 "avg_launch_ms": conv_ms / max(n_launch, 1),
                 "gflop_per_launch": conv_flops / max(n_launch, 1) / 1e9,

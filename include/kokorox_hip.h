@@ -114,6 +114,9 @@ int kx_set_utterance_base(kx_model* m, uint64_t utt_base);
  * FLOPs (2*Cout*Cin*k*columns per launch) since the last read. */
 int kx_profile_enable(kx_model* m, int on);
 int kx_profile_read(kx_model* m, int64_t* launches, double* total_ms, double* total_flops);
+/* Per-launch records of the last kx_profile_read: out[i*9 + 0..8] = GEMM rows, Cin, taps, dilation,
+ * stride, store form, summed columns, FLOPs, milliseconds.  out = NULL returns the count only. */
+int kx_profile_detail(kx_model* m, double* out, int64_t cap_rows, int64_t* n_rows);
 
 /* ---- test hooks (used by tests/ only) --------------------------------------------- */
 

@@ -168,6 +168,21 @@ int kx_profile_read(kx_model* m, int64_t* launches, double* total_ms, double* to
     });
 }
 
+int kx_profile_detail(kx_model* m, double* out, int64_t cap_rows, int64_t* n_rows) {
+    return guarded(m, [&](Model& M) {
+        KX_REQUIRE(n_rows, "profile_detail: null argument");
+        *n_rows = (int64_t)M.prof_detail.size();
+        if (!out) return;
+        int64_t n = *n_rows < cap_rows ? *n_rows : cap_rows;
+        for (int64_t i = 0; i < n; ++i) {
+            const auto& r = M.prof_detail[i];
+            double* o = out + i * 9;
+            o[0] = r.rows; o[1] = r.Cin; o[2] = r.K; o[3] = r.dil; o[4] = r.stride; o[5] = r.store;
+            o[6] = r.cols; o[7] = r.flops; o[8] = r.ms;
+        }
+    });
+}
+
 int kx_debug_tap(kx_model* m, const char* name, int b, float* out, int64_t out_cap, int32_t* C, int32_t* L) {
     return guarded(m, [&](Model& M) {
         KX_REQUIRE(name && C && L, "debug_tap: null argument");

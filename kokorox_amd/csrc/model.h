@@ -99,6 +99,8 @@ class Model {
     void set_pinned(const int32_t* pattern, int n);
     void profile_enable(bool on);
     void profile_read(int64_t* launches, double* ms, double* flops);
+    struct ProfRec { int rows, Cin, K, dil, stride, store; double cols, flops; float ms; };
+    std::vector<ProfRec> prof_detail;  // filled by profile_read (one record per timed launch)
     const Tap* find_tap(const std::string& name) const;
 
     std::mutex mu;
@@ -160,6 +162,7 @@ class Model {
     std::vector<hipEvent_t> ev_;
     size_t ev_used_ = 0;
     double prof_flops_ = 0.0;
+    std::vector<ProfRec> prof_recs_;
     int64_t prof_launches_ = 0;
 };
 

@@ -359,6 +359,7 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
         for (int b = 0; b < B_; ++b) cols += (double)hl[b] * lm.mul + lm.add + (o.store == ST_UPSCATTER ? 1 : 0);
         prof_flops_ += 2.0 * w.rows * w.Cin * w.K * cols;
         prof_launches_ += 1;
+        prof_recs_.push_back(ProfRec{w.rows, w.Cin, w.K, o.dil, o.stride, o.store, cols, 2.0 * w.rows * w.Cin * w.K * cols, 0.f});
         if (ev_used_ + 2 > ev_.size()) {
             for (int i = 0; i < 64; ++i) {
                 hipEvent_t e;
@@ -520,6 +521,7 @@ void Model::set_pinned(const int32_t* pattern, int n) {
 void Model::profile_enable(bool on) {
     sync();
     prof_on_ = on;
+    prof_recs_.clear();
     ev_used_ = 0;
     prof_flops_ = 0;
     prof_launches_ = 0;
@@ -533,7 +535,10 @@ void Model::profile_read(int64_t* launches, double* ms, double* flops) {
         float t = 0;
         KX_HIP(hipEventElapsedTime(&t, ev_[i], ev_[i + 1]));
         total += t;
+        if (i / 2 < prof_recs_.size()) prof_recs_[i / 2].ms = t;
     }
+    prof_detail.swap(prof_recs_);
+    prof_recs_.clear();
     *launches = prof_launches_;
     *ms = total;
     *flops = prof_flops_;

@@ -62,6 +62,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_set_utterance_base": (i32, [vp, u64]),
         "kx_profile_enable": (i32, [vp, i32]),
         "kx_profile_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "kx_profile_detail": (i32, [vp, vp, i64, C.POINTER(i64)]),
         "kx_debug_tap": (i32, [vp, cp, i32, vp, i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "kx_test_conv1d": (i32, [i32, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp,
                                  i32, cp, sz]),
@@ -80,7 +81,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 ABI_SYMBOLS = [
     "kx_version", "kx_init", "kx_create", "kx_create_from_device_blob", "kx_destroy", "kx_last_error", "kx_infer",
     "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_set_utterance_base",
-    "kx_profile_enable", "kx_profile_read", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source",
+    "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source",
 ]
 
 
@@ -198,6 +199,14 @@ class HipKoko:
         n, ms, fl = C.c_int64(0), C.c_double(0), C.c_double(0)
         self._check(self._lib.kx_profile_read(self._h, C.byref(n), C.byref(ms), C.byref(fl)))
         return int(n.value), float(ms.value), float(fl.value)
+
+    def profile_detail(self) -> np.ndarray:
+        """[n, 9] rows of the last profile_read: rows, Cin, taps, dil, stride, store, cols, flops, ms."""
+        n = C.c_int64(0)
+        self._check(self._lib.kx_profile_detail(self._h, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 9), dtype=np.float64)
+        self._check(self._lib.kx_profile_detail(self._h, _ptr(out), n.value, C.byref(n)))
+        return out[: n.value]
 
     def tap(self, name: str, b: int = 0) -> np.ndarray:
         c, l = C.c_int32(0), C.c_int32(0)
