@@ -23,7 +23,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/F16 MFMA, dense (no sparsity)
 _T0 = time.perf_counter()
 
 
@@ -80,6 +81,28 @@ def pmc_traffic(B, T, F):
         if (w.get("batch"), w.get("tokens"), w.get("frames")) == (B, T, F):
             best = d
     return None if best is None else best["traffic_bytes_per_launch"]
+
+
+def roofline(f16x3, conv_flops, conv_ms, n_launch, steps, wall, B, T, F):
+    """Dominant kernel = the BM=128 family of the conv1d implicit-GEMM kernel (HIP events in the library).
+
+    achieved = ALGORITHMIC FLOPs (2*Cout*Cin*k*L per launch) / measured time.  In f16x3 mode every
+    algorithmic multiply-add is issued as 3 f16 MFMAs, so the matrix pipe does 3x these FLOPs; the peak
+    quoted is the plain dense f16 MFMA peak and `frac` is algorithmic/peak (pipe utilisation = 3*frac)."""
+    if conv_ms <= 0:
+        return None
+    ach = conv_flops / (conv_ms * 1e-3) / 1e12
+    peak = PEAK_F16_MFMA_TFLOPS if f16x3 else PEAK_F32_MFMA_TFLOPS
+    kern = ("kx::conv1d_f16x3_kernel<128,{256|128},2,2,ACT> (f16 32x32x16 MFMA x3, implicit GEMM)" if f16x3
+            else "kx::conv1d_mfma_kernel<128,128,2,2> (f32 32x32x2 MFMA implicit GEMM)")
+    out = {"bound": "mfma", "kernel": kern, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+           "traffic": pmc_traffic(B, T, F) if not f16x3 else None,
+           "launches_per_step": n_launch / max(steps, 1), "avg_launch_ms": conv_ms / max(n_launch, 1),
+           "gflop_per_launch": conv_flops / max(n_launch, 1) / 1e9, "kernel_share_of_wall": conv_ms * 1e-3 / wall}
+    if f16x3:
+        out["mfma_issue_factor"] = 3
+        out["matrix_pipe_utilisation"] = 3 * ach / peak
+    return out
 
 
 def cpu_baseline(blob_path: str, n_utts: int, n_phonemes: int, pinned):
@@ -192,6 +215,7 @@ def main():
     wall = time.perf_counter() - t0
     progress(f"{a.steps} timed steps: {wall:.3f} s")
     n_launch, conv_ms, conv_flops = model.profile_read()
+    f16x3 = model.get_conv_mode() == 1
     if a.detail and rank == 0:
         det = model.profile_detail()
         per = len(det) // max(a.steps, 1)
@@ -256,7 +280,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (f16x3 split MFMA: 3 f16 MFMAs per product on hi/lo halves, f32 accumulate)" if f16x3 else "f32",
             "data": "synthetic (seeded random-init Kokoro-82M weights, uniform phoneme ids, N(0,0.1) voice rows)",
             "config": {
                 "workload": f"batch={B}/GPU synthetic {a.phonemes}-phoneme utterances (T={T}), durations pinned "
@@ -269,19 +293,7 @@ def main():
             "finite": finite,
             "weight_broadcast_s": t_bcast,
             "model_tflops": flops_per_utt * world * B * a.steps / wall / 1e12,
-            "roofline": {
-                "bound": "mfma",
-                "kernel": "kx::conv1d_mfma_kernel<128,128,2,2> (f32 32x32x2 MFMA implicit GEMM)",
-                "achieved": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
-                "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": (conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if conv_ms > 0 else None,
-                "traffic": pmc_traffic(B, T, F),
-                "launches_per_step": n_launch / max(a.steps, 1),
-                "avg_launch_ms": conv_ms / max(n_launch, 1),
-                "gflop_per_launch": conv_flops / max(n_launch, 1) / 1e9,
-                "kernel_share_of_wall": conv_ms * 1e-3 / wall,
-            },
+            "roofline": roofline(f16x3, conv_flops, conv_ms, n_launch, a.steps, wall, B, T, F),
             "free_running": free,
         }
         if world == 1 and a.cpu_utts > 0:

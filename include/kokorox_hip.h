@@ -104,6 +104,12 @@ int kx_sync(kx_model* m);
  * runs).  n = 0 clears it. */
 int kx_set_pinned_durations(kx_model* m, const int32_t* pattern, int n);
 
+/* Contraction arithmetic of the conv/linear kernel: 0 = f32 MFMA (v_mfma_f32_32x32x2_f32, exact f32
+ * products), 1 = f16x3 split MFMA (three v_mfma_f32_32x32x16_f16 per K-step on hi/lo halves, ~22
+ * significant bits per product, f32 accumulation).  Default 1; env KOKOROX_CONV=f32 selects 0 at create. */
+int kx_set_conv_mode(kx_model* m, int mode);
+int kx_get_conv_mode(kx_model* m);
+
 /* First utterance index used for the noise stream of the next calls (default 0). */
 int kx_set_utterance_base(kx_model* m, uint64_t utt_base);
 
@@ -127,11 +133,12 @@ int kx_debug_tap(kx_model* m, const char* name, int b, float* out, int64_t out_c
 
 /* Stand-alone run of the conv1d MFMA kernel on host arrays (x [B,Cin,L], w [Cout,Cin,k]
  * or, for transposed = 1, [Cin,Cout,k]); y must hold B*Cout*Lout floats.  act: 0 none,
- * 1 leaky(slope), 2 snake(alpha[Cin]); norm = optional [3,B,Cin] (mean, scale, shift). */
+ * 1 leaky(slope), 2 snake(alpha[Cin]); norm = optional [3,B,Cin] (mean, scale, shift);
+ * mode as in kx_set_conv_mode. */
 int kx_test_conv1d(int device_id, const float* x, int B, int Cin, int L, const float* w,
                    const float* bias, int Cout, int k, int stride, int pad, int dil,
                    int transposed, int act, float slope, const float* alpha,
-                   const float* norm, float* y, int Lout, char* err, size_t err_len);
+                   const float* norm, float* y, int Lout, int mode, char* err, size_t err_len);
 
 /* Stand-alone bidirectional LSTM (hidden 256): x [B,L,n_in] -> y [B,L,512]. */
 int kx_test_lstm(int device_id, const float* x, int B, int L, int n_in, const float* w_ih,

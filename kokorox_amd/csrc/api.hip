@@ -153,6 +153,16 @@ int kx_set_pinned_durations(kx_model* m, const int32_t* pattern, int n) {
     return guarded(m, [&](Model& M) { M.set_pinned(pattern, n); });
 }
 
+int kx_set_conv_mode(kx_model* m, int mode) {
+    return guarded(m, [&](Model& M) {
+        KX_REQUIRE(mode == kx::CONV_F32 || mode == kx::CONV_F16X3, "conv mode must be 0 (f32 MFMA) or 1 (f16x3 split MFMA)");
+        M.sync();
+        M.conv_mode = mode;
+    });
+}
+
+int kx_get_conv_mode(kx_model* m) { return (m && m->m) ? m->m->conv_mode : -1; }
+
 int kx_set_utterance_base(kx_model* m, uint64_t utt_base) {
     return guarded(m, [&](Model& M) { M.utt_base = utt_base; });
 }
@@ -202,7 +212,7 @@ int kx_debug_tap(kx_model* m, const char* name, int b, float* out, int64_t out_c
 
 int kx_test_conv1d(int device_id, const float* x, int B, int Cin, int L, const float* w, const float* bias, int Cout,
                    int k, int stride, int pad, int dil, int transposed, int act, float slope, const float* alpha,
-                   const float* norm, float* y, int Lout, char* err, size_t err_len) {
+                   const float* norm, float* y, int Lout, int mode, char* err, size_t err_len) {
     return guarded_free(err, err_len, [&] {
         check_device(device_id);
         KX_REQUIRE(x && w && y && B > 0 && Cin > 0 && Cout > 0 && L > 0 && Lout > 0 && k > 0, "test_conv1d: bad argument");
@@ -269,7 +279,24 @@ int kx_test_conv1d(int device_id, const float* x, int B, int Cin, int L, const f
         a.y_ld = Lout;
         a.out_mul = 1.f;
         a.out_div = 1.f;
-        kx::launch_conv1d(a, BM, B, transposed ? L + 1 : Lout, nullptr);
+        if (mode == kx::CONV_F16X3) {
+            const float amax = kx::device_absmax(dw, (long)Cout * Cin * k, nullptr);
+            const int ws = kx::pick_weight_shift(amax);
+            const int Kp = transposed ? 2 : k;
+            void* p16 = dm.get<unsigned short>(kx::packed_conv16_halves(rows, Cin, Kp, BM));
+            if (transposed)
+                kx::launch_pack_convT16(dw, p16, Cin, Cout, stride, BM, std::ldexp(1.0f, ws), nullptr);
+            else {
+                kx::PackSrc src{{dw, nullptr, nullptr}, {Cout, 0, 0}};
+                kx::launch_pack_conv16(src, p16, Cout, Cin, k, BM, std::ldexp(1.0f, ws), nullptr);
+            }
+            a.w16 = p16;
+            a.n_chunks16 = (Cin + 15) / 16;
+            a.w_unscale = std::ldexp(1.0f, -ws);
+            kx::launch_conv1d_f16x3(a, BM, B, transposed ? L + 1 : Lout, nullptr);
+        } else {
+            kx::launch_conv1d(a, BM, B, transposed ? L + 1 : Lout, nullptr);
+        }
         KX_HIP(hipDeviceSynchronize());
         KX_HIP(hipMemcpy(y, dy, (size_t)B * Cout * Lout * 4, hipMemcpyDeviceToHost));
     });

@@ -26,11 +26,10 @@
 // Epilogue: bias, residual add, accumulate, scale / divide, optional gelu_new, and three
 // store forms: channel-major, time-major (LSTM gate pre-activations), and the polyphase
 // scatter of a transposed convolution (row (p,co), column q -> out[co][s*q + p - pad]).
+#include "conv_epilogue.h"
 #include "kx_common.h"
 
 namespace kx {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 __device__ __forceinline__ float conv_in_act(float v, int act, float slope, float al, float inv_al) {
     if (act == ACT_LEAKY) return v > 0.f ? v : v * slope;
@@ -39,11 +38,6 @@ __device__ __forceinline__ float conv_in_act(float v, int act, float slope, floa
         return v + inv_al * (s * s);
     }
     return v;
-}
-
-__device__ __forceinline__ float gelu_new(float x) {
-    const float c = 0.7978845608028654f;
-    return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * (x * x * x))));
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -149,48 +143,8 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue ----------------------------------------------------------------------
-    // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = t0 + wn * (NT * 32) + nt * 32 + r;
-            if (col >= ncols) continue;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = ct * BM + wm * (MT * 32) + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row >= a.Cout) continue;
-                float v = acc[mt][nt][e];
-                if (a.store == ST_UPSCATTER) {
-                    const int p = row / a.up_cout;
-                    const int co = row - p * a.up_cout;
-                    const int tout = a.up_s * col + p - a.up_pad;
-                    if (tout < 0 || tout >= Lout) continue;
-                    if (a.bias) v += a.bias[co];
-                    const long yi = (long)b * a.y_bs + (long)co * a.y_ld + tout + a.up_off;
-                    float o = v;
-                    if (a.resid) o += a.resid[(long)b * a.r_bs + (long)co * a.r_ld + tout + a.up_off];
-                    a.y[yi] = o;
-                    if (a.up_reflect && tout == 1) {  // ReflectionPad1d((1,0)): out[0] = up[1]
-                        float o0 = v;
-                        if (a.resid) o0 += a.resid[(long)b * a.r_bs + (long)co * a.r_ld];
-                        a.y[(long)b * a.y_bs + (long)co * a.y_ld] = o0;
-                    }
-                    continue;
-                }
-                if (a.bias) v += a.bias[row];
-                const long yi = (a.store == ST_TMAJOR) ? ((long)b * a.y_bs + (long)col * a.y_ld + row)
-                                                       : ((long)b * a.y_bs + (long)row * a.y_ld + col);
-                if (a.resid) v += a.resid[(long)b * a.r_bs + (long)row * a.r_ld + col];
-                if (a.accum) v += a.y[yi];
-                v *= a.out_mul;
-                if (a.out_div != 1.0f) v = v / a.out_div;
-                if (a.epi == EPI_GELU_NEW) v = gelu_new(v);
-                a.y[yi] = v;
-            }
-        }
-    }
+    // ---- epilogue (conv_epilogue.h) -------------------------------------------------------------
+    conv_store_tile<MT, NT>(a, acc, 1.0f, b, ct * BM + wm * (MT * 32), t0 + wn * (NT * 32), r, h, ncols, Lout);
 }
 
 template <int BM, int BN, int WM, int WN>

@@ -2,7 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <cstdio>
 #include <stdexcept>
 #include <string>
@@ -76,6 +78,11 @@ struct ConvArgs {
     int epi;
     int store;
     int up_s, up_pad, up_off, up_reflect, up_cout;
+    // f16x3 path (conv_f16x3.hip): split-f16 weight image, 16-channel chunks, 2^-ws to undo the weight scale
+    const void* w16;
+    int n_chunks16;
+    float w_unscale;
+    int dbg;  // timing ablations (env KX_DBG): 1 skip input staging, 2 skip weight copies, 4 skip MFMA, 8 skip epilogue
 };
 
 struct ConvShape {
@@ -95,6 +102,15 @@ void launch_pack_conv(const PackSrc& src, float* dst, int Cout, int Cin, int K, 
 // ConvTranspose1d weight [Cin][Cout][k], k == 2*s  ->  polyphase GEMM rows (p, co), 2 taps
 void launch_pack_convT(const float* w, float* dst, int Cin, int Cout, int s, int BM, hipStream_t s_);
 size_t packed_conv_floats(int rows, int Cin, int K, int BM);
+
+// f16x3 split path
+enum ConvMode { CONV_F32 = 0, CONV_F16X3 = 1 };
+void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStream_t s);
+size_t packed_conv16_halves(int rows, int Cin, int K, int BM);
+float device_absmax(const float* p, long n, hipStream_t s);
+int pick_weight_shift(float absmax);
+void launch_pack_conv16(const PackSrc& src, void* dst, int Cout, int Cin, int K, int BM, float wscale, hipStream_t s);
+void launch_pack_convT16(const float* w, void* dst, int Cin, int Cout, int sd, int BM, float wscale, hipStream_t s);
 
 // ---- everything else (kernels_misc.hip) ----------------------------------------------
 void launch_vec_add(const float* a, const float* b, float* out, int n, hipStream_t s);

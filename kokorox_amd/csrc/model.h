@@ -20,6 +20,9 @@ struct ConvW {
     const float* bias = nullptr;  // [Cout] or null
     int rows = 0, Cin = 0, K = 0, BM = 0, n_chunks = 0;
     int up_s = 0, up_cout = 0;  // polyphase transposed conv
+    const void* w16 = nullptr;  // split-f16 image (conv_f16x3.hip)
+    int n_chunks16 = 0;
+    float unscale = 1.f;        // 2^-ws
 };
 
 struct LstmW {
@@ -106,6 +109,7 @@ class Model {
     std::mutex mu;
     std::string last_error;
     uint64_t utt_base = 0;
+    int conv_mode = CONV_F16X3;
     int device;
 
   private:
@@ -114,6 +118,7 @@ class Model {
     const TensorInfo& info(const std::string& name) const;
     bool has(const std::string& name) const { return table_.count(name) != 0; }
     float* dev_alloc(size_t floats);
+    void pack16(ConvW& c, const PackSrc& src, const float* wT, int n_src_floats[3]);
     ConvW make_conv(const std::string& name, bool bias = true);
     ConvW make_conv_cat(const std::vector<std::string>& names);
     ConvW make_convT(const std::string& name, int stride);

@@ -12,6 +12,7 @@ static constexpr float RSQRT2 = 0.70710678118654752f;
 static inline int up4(int x) { return (x + 3) & ~3; }
 
 Model::Model(int dev) : device(dev) {
+    if (const char* e = getenv("KOKOROX_CONV")) conv_mode = (strcmp(e, "f32") == 0) ? CONV_F32 : CONV_F16X3;
     KX_HIP(hipSetDevice(device));
     KX_HIP(hipStreamCreate(&stream_));
     init_dft_tables();
@@ -124,6 +125,27 @@ float* Model::dev_alloc(size_t floats) {
     return static_cast<float*>(p);
 }
 
+// split-f16 image of the same weights (normal convs: src; transposed: wT [Cin][Cout][2s])
+void Model::pack16(ConvW& c, const PackSrc& src, const float* wT, int n_src_floats[3]) {
+    float amax = 0.f;
+    if (wT) {
+        amax = device_absmax(wT, n_src_floats[0], stream_);
+    } else {
+        for (int i = 0; i < 3; ++i)
+            if (src.p[i]) amax = std::fmax(amax, device_absmax(src.p[i], n_src_floats[i], stream_));
+    }
+    const int ws = pick_weight_shift(amax);
+    c.unscale = std::ldexp(1.0f, -ws);
+    c.n_chunks16 = (c.Cin + 15) / 16;
+    const size_t halves = packed_conv16_halves(c.rows, c.Cin, c.K, c.BM);
+    void* p = dev_alloc((halves + 1) / 2);
+    if (wT)
+        launch_pack_convT16(wT, p, c.Cin, c.up_cout, c.up_s, c.BM, std::ldexp(1.0f, ws), stream_);
+    else
+        launch_pack_conv16(src, p, c.rows, c.Cin, c.K, c.BM, std::ldexp(1.0f, ws), stream_);
+    c.w16 = p;
+}
+
 ConvW Model::make_conv(const std::string& name, bool bias) {
     const TensorInfo& ti = info(name + ".weight");
     ConvW c;
@@ -137,6 +159,8 @@ ConvW Model::make_conv(const std::string& name, bool bias) {
     launch_pack_conv(src, p, c.rows, c.Cin, c.K, c.BM, stream_);
     c.w = p;
     c.bias = (bias && has(name + ".bias")) ? wt(name + ".bias") : nullptr;
+    int nf[3] = {c.rows * c.Cin * c.K, 0, 0};
+    pack16(c, src, nullptr, nf);
     return c;
 }
 
@@ -157,6 +181,8 @@ ConvW Model::make_conv_cat(const std::vector<std::string>& names) {
     float* p = dev_alloc(packed_conv_floats(c.rows, c.Cin, c.K, c.BM));
     launch_pack_conv(src, p, c.rows, c.Cin, c.K, c.BM, stream_);
     c.w = p;
+    int nf[3] = {src.rows[0] * c.Cin * c.K, src.rows[1] * c.Cin * c.K, src.rows[2] * c.Cin * c.K};
+    pack16(c, src, nullptr, nf);
     float* bias = dev_alloc(c.rows);
     int r0 = 0;
     for (size_t i = 0; i < names.size(); ++i) {
@@ -183,6 +209,8 @@ ConvW Model::make_convT(const std::string& name, int stride) {
     launch_pack_convT(wt(name + ".weight"), p, c.Cin, c.up_cout, stride, c.BM, stream_);
     c.w = p;
     c.bias = wt(name + ".bias");
+    int nf[3] = {c.Cin * c.up_cout * 2 * stride, 0, 0};
+    pack16(c, PackSrc{{nullptr, nullptr, nullptr}, {0, 0, 0}}, wt(name + ".weight"), nf);
     return c;
 }
 
@@ -199,6 +227,8 @@ LstmW Model::make_lstm(const std::string& name) {
     PackSrc src{{wt(name + ".weight_ih_l0"), wt(name + ".weight_ih_l0_reverse"), nullptr}, {1024, 1024, 0}};
     launch_pack_conv(src, p, 2048, c.Cin, 1, 128, stream_);
     c.w = p;
+    int nf[3] = {1024 * c.Cin, 1024 * c.Cin, 0};
+    pack16(c, src, nullptr, nf);
     float* bias = dev_alloc(2048);
     launch_vec_add(wt(name + ".bias_ih_l0"), wt(name + ".bias_hh_l0"), bias, 1024, stream_);
     launch_vec_add(wt(name + ".bias_ih_l0_reverse"), wt(name + ".bias_hh_l0_reverse"), bias + 1024, 1024, stream_);
@@ -351,6 +381,12 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     a.up_off = o.up_off;
     a.up_reflect = o.up_reflect;
     a.up_cout = w.up_cout ? w.up_cout : 1;
+    a.w16 = w.w16;
+    a.n_chunks16 = w.n_chunks16;
+    a.w_unscale = w.unscale;
+    static const int dbg_env = getenv("KX_DBG") ? atoi(getenv("KX_DBG")) : 0;
+    a.dbg = dbg_env;
+    const bool f16 = conv_mode == CONV_F16X3;
     const int max_cols = (o.store == ST_UPSCATTER) ? in.Lmax + 1 : out.Lmax;
     if (prof_on_ && w.BM == 128) {  // the dominant instantiation conv1d_mfma_kernel<128,128,2,2>
         const LenMap& lm = (o.store == ST_UPSCATTER) ? in.len : out.len;
@@ -368,11 +404,13 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
             }
         }
         KX_HIP(hipEventRecord(ev_[ev_used_], stream_));
-        launch_conv1d(a, w.BM, B_, max_cols, stream_);
+        if (f16) launch_conv1d_f16x3(a, w.BM, B_, max_cols, stream_);
+        else launch_conv1d(a, w.BM, B_, max_cols, stream_);
         KX_HIP(hipEventRecord(ev_[ev_used_ + 1], stream_));
         ev_used_ += 2;
     } else {
-        launch_conv1d(a, w.BM, B_, max_cols, stream_);
+        if (f16) launch_conv1d_f16x3(a, w.BM, B_, max_cols, stream_);
+        else launch_conv1d(a, w.BM, B_, max_cols, stream_);
     }
 }
 

@@ -60,12 +60,14 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_sync": (i32, [vp]),
         "kx_set_pinned_durations": (i32, [vp, vp, i32]),
         "kx_set_utterance_base": (i32, [vp, u64]),
+        "kx_set_conv_mode": (i32, [vp, i32]),
+        "kx_get_conv_mode": (i32, [vp]),
         "kx_profile_enable": (i32, [vp, i32]),
         "kx_profile_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "kx_profile_detail": (i32, [vp, vp, i64, C.POINTER(i64)]),
         "kx_debug_tap": (i32, [vp, cp, i32, vp, i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "kx_test_conv1d": (i32, [i32, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp,
-                                 i32, cp, sz]),
+                                 i32, i32, cp, sz]),
         "kx_test_lstm": (i32, [i32, vp, i32, i32, i32] + [vp] * 9 + [cp, sz]),
         "kx_test_source": (i32, [i32, vp, i32, i32, vp, f32, u64, u64, i32, vp, cp, sz]),
     }
@@ -81,6 +83,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 ABI_SYMBOLS = [
     "kx_version", "kx_init", "kx_create", "kx_create_from_device_blob", "kx_destroy", "kx_last_error", "kx_infer",
     "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_set_utterance_base",
+    "kx_set_conv_mode", "kx_get_conv_mode",
     "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source",
 ]
 
@@ -189,6 +192,13 @@ class HipKoko:
         p = np.ascontiguousarray(pattern, dtype=np.int32)
         self._check(self._lib.kx_set_pinned_durations(self._h, _ptr(p), p.shape[0]))
 
+    def set_conv_mode(self, mode: int):
+        """0 = f32 MFMA, 1 = f16x3 split MFMA (default)."""
+        self._check(self._lib.kx_set_conv_mode(self._h, mode))
+
+    def get_conv_mode(self) -> int:
+        return int(self._lib.kx_get_conv_mode(self._h))
+
     def set_utterance_base(self, base: int):
         self._check(self._lib.kx_set_utterance_base(self._h, base))
 
@@ -239,10 +249,15 @@ def _err_call(fn, *args):
         raise KokoroxHipError(rc, err.value.decode())
 
 
+CONV_F32, CONV_F16X3 = 0, 1
+
+
 def conv1d(x, w, bias=None, stride=1, pad=0, dil=1, transposed=False, act=0, slope=0.0, alpha=None, norm=None,
-           device=0):
+           device=0, mode=None):
     """Run the MFMA conv kernel alone: x [B,Cin,L], w [Cout,Cin,k] ([Cin,Cout,k] if transposed)."""
     lib = load_library()
+    if mode is None:
+        mode = CONV_F32 if os.environ.get("KOKOROX_CONV", "") == "f32" else CONV_F16X3
     x, w = _f32(x), _f32(w)
     B, Cin, L = x.shape
     k = w.shape[2]
@@ -255,7 +270,7 @@ def conv1d(x, w, bias=None, stride=1, pad=0, dil=1, transposed=False, act=0, slo
     y = np.zeros((B, Cout, Lout), dtype=np.float32)
     bias, alpha, norm = _f32(bias), _f32(alpha), _f32(norm)
     _err_call(lib.kx_test_conv1d, device, _ptr(x), B, Cin, L, _ptr(w), _ptr(bias), Cout, k, stride, pad, dil,
-              1 if transposed else 0, act, float(slope), _ptr(alpha), _ptr(norm), _ptr(y), Lout)
+              1 if transposed else 0, act, float(slope), _ptr(alpha), _ptr(norm), _ptr(y), Lout, mode)
     return y
 
 

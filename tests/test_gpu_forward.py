@@ -37,7 +37,18 @@ def _inputs(token_counts, seed0=10):
     return ids, styles
 
 
-def test_ragged_batch_matches_oracle(hip_model, oracle):
+@pytest.mark.parametrize("mode", [pytest.param(0, id="f32"), pytest.param(1, id="f16x3")])
+def test_ragged_batch_matches_oracle(hip_model, oracle, mode):
+    from kokorox_amd import hip_koko as hk
+    default_mode = hip_model.get_conv_mode()
+    hip_model.set_conv_mode(mode)
+    try:
+        _ragged_batch_vs_oracle(hip_model, oracle)
+    finally:
+        hip_model.set_conv_mode(default_mode)
+
+
+def _ragged_batch_vs_oracle(hip_model, oracle):
     from kokorox_amd import hip_koko as hk
     counts = [21, 9, 14]
     ids, styles = _inputs(counts)

@@ -1,7 +1,8 @@
 """GPU: each hand-written kernel, alone, through the C ABI test hooks, against torch CPU in float64.
 
-Tolerances: f32 MFMA accumulation is a k-ordered fmaf chain (cdna_hip_programming.md §3), so the
-error bound is ~1e-7 * sum|a*b|; 2e-5 absolute on O(1) outputs with K up to 3270 leaves >5x margin.
+Both contraction modes are covered: f32 MFMA (a k-ordered fmaf chain, error ~1e-7 * sum|a*b|) and the
+f16x3 split MFMA (three f16 MFMAs per step on hi/lo halves, ~2^-22 per product).  2e-5 absolute on
+O(1) outputs with K up to 3270 leaves margin for both.
 """
 import numpy as np
 import pytest
@@ -26,22 +27,27 @@ CONV_CASES = [
 ]
 
 
+MODES = [pytest.param(0, id="f32"), pytest.param(1, id="f16x3")]
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("B,Cin,Cout,L,k,s,p,d", CONV_CASES)
-def test_conv1d_mfma(B, Cin, Cout, L, k, s, p, d):
+def test_conv1d_mfma(B, Cin, Cout, L, k, s, p, d, mode):
     from kokorox_amd import hip_koko as hk
     rng = np.random.default_rng(B * 1000 + Cin + L)
     x = rng.standard_normal((B, Cin, L), dtype=np.float32)
     w = (rng.standard_normal((Cout, Cin, k), dtype=np.float32) / np.sqrt(Cin * k)).astype(np.float32)
     b = rng.standard_normal(Cout, dtype=np.float32)
-    y = hk.conv1d(x, w, b, stride=s, pad=p, dil=d)
+    y = hk.conv1d(x, w, b, stride=s, pad=p, dil=d, mode=mode)
     ref = F.conv1d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
                    stride=s, padding=p, dilation=d).numpy()
     assert y.shape == ref.shape
     assert np.abs(y - ref).max() < 2e-5
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("act", [1, 2])
-def test_conv1d_fused_adain_activation(act):
+def test_conv1d_fused_adain_activation(act, mode):
     """AdaIN affine + leaky / snake applied while staging the input tile; zero padding comes AFTER."""
     from kokorox_amd import hip_koko as hk
     rng = np.random.default_rng(act)
@@ -50,7 +56,7 @@ def test_conv1d_fused_adain_activation(act):
     w = (rng.standard_normal((Cout, Cin, k), dtype=np.float32) / np.sqrt(Cin * k)).astype(np.float32)
     norm = rng.standard_normal((3, B, Cin), dtype=np.float32)
     alpha = (rng.random(Cin, dtype=np.float32) + 0.5).astype(np.float32)
-    y = hk.conv1d(x, w, None, pad=3, act=act, slope=0.2, alpha=alpha, norm=norm)
+    y = hk.conv1d(x, w, None, pad=3, act=act, slope=0.2, alpha=alpha, norm=norm, mode=mode)
     n = torch.from_numpy(norm).double()
     xt = (torch.from_numpy(x).double() - n[0][:, :, None]) * n[1][:, :, None] + n[2][:, :, None]
     if act == 2:
@@ -62,15 +68,16 @@ def test_conv1d_fused_adain_activation(act):
     assert np.abs(y - ref).max() < 3e-5
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("Cin,Cout,L,s", [(16, 24, 37, 10), (256, 128, 50, 6), (512, 256, 21, 10), (8, 8, 1, 6)])
-def test_conv_transpose_polyphase(Cin, Cout, L, s):
+def test_conv_transpose_polyphase(Cin, Cout, L, s, mode):
     from kokorox_amd import hip_koko as hk
     rng = np.random.default_rng(Cin + L)
     k = 2 * s
     x = rng.standard_normal((2, Cin, L), dtype=np.float32)
     w = (rng.standard_normal((Cin, Cout, k), dtype=np.float32) / np.sqrt(Cin * 2)).astype(np.float32)
     b = rng.standard_normal(Cout, dtype=np.float32)
-    y = hk.conv1d(x, w, b, stride=s, pad=(k - s) // 2, transposed=True)
+    y = hk.conv1d(x, w, b, stride=s, pad=(k - s) // 2, transposed=True, mode=mode)
     ref = F.conv_transpose1d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
                              stride=s, padding=(k - s) // 2).numpy()
     assert y.shape == ref.shape
@@ -79,6 +86,7 @@ def test_conv_transpose_polyphase(Cin, Cout, L, s):
 
 @pytest.mark.parametrize("L,n_in", [(19, 72), (1, 640), (130, 512)])
 def test_bilstm(L, n_in):
+    """(the input projection runs on the f32 MFMA kernel in this hook)"""
     from kokorox_amd import hip_koko as hk
     torch.manual_seed(L)
     m = torch.nn.LSTM(n_in, 256, 1, batch_first=True, bidirectional=True).double()
