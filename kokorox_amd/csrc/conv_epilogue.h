@@ -19,30 +19,55 @@ template <int MT, int NT>
 __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)[MT][NT], float acc_scale, int b,
                                                 int row0, int col0, int r, int h, int ncols, int Lout) {
     if (a.store == ST_NORMAL) {
+        // Latency-bound read-modify-write of the tile: issue the residual / accumulate loads of 8 rows x NT
+        // columns back to back (addresses clamped so the loads need no branches), then combine and store.
         const bool has_res = a.resid != nullptr, has_bias = a.bias != nullptr;
         const bool accum = a.accum != 0, gelu = a.epi == EPI_GELU_NEW, do_div = a.out_div != 1.0f;
         float* yb = a.y + (long)b * a.y_bs;
-        const float* rb = has_res ? a.resid + (long)b * a.r_bs : nullptr;
+        const float* rb = has_res ? a.resid + (long)b * a.r_bs : yb;
+        const int cmax = ncols - 1, rmax = a.Cout - 1;
+        int colc[NT];
+        bool cok[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = col0 + nt * 32 + r;
+            cok[nt] = col < ncols;
+            colc[nt] = col < cmax ? col : cmax;
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = row0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row >= a.Cout) continue;
-                const float bv = has_bias ? a.bias[row] : 0.f;
-                float* yr = yb + (long)row * a.y_ld;
-                const float* rr = has_res ? rb + (long)row * a.r_ld : nullptr;
+            for (int eg = 0; eg < 2; ++eg) {
+                float rv[8][NT], yv[8][NT], bv[8];
+                long yo[8];
+                bool rok[8];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int col = col0 + nt * 32 + r;
-                    if (col >= ncols) continue;
-                    float v = acc[mt][nt][e] * acc_scale + bv;
-                    if (has_res) v += rr[col];
-                    if (accum) v += yr[col];
-                    v *= a.out_mul;
-                    if (do_div) v = v / a.out_div;
-                    if (gelu) v = gelu_new_f(v);
-                    yr[col] = v;
+                for (int e8 = 0; e8 < 8; ++e8) {
+                    const int e = eg * 8 + e8;
+                    const int row = row0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    rok[e8] = row < a.Cout;
+                    const int rowc = row < rmax ? row : rmax;
+                    yo[e8] = (long)rowc * a.y_ld;
+                    bv[e8] = has_bias ? a.bias[rowc] : 0.f;
+                    const long ro = (long)rowc * (has_res ? a.r_ld : a.y_ld);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        rv[e8][nt] = has_res ? rb[ro + colc[nt]] : 0.f;
+                        yv[e8][nt] = accum ? yb[yo[e8] + colc[nt]] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        float v = acc[mt][nt][eg * 8 + e8] * acc_scale + bv[e8];
+                        if (has_res) v += rv[e8][nt];
+                        if (accum) v += yv[e8][nt];
+                        v *= a.out_mul;
+                        if (do_div) v = v / a.out_div;
+                        if (gelu) v = gelu_new_f(v);
+                        if (rok[e8] && cok[nt]) yb[yo[e8] + colc[nt]] = v;
+                    }
                 }
             }
         }

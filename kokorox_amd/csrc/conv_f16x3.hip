@@ -25,7 +25,7 @@ using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using half2v = __attribute__((ext_vector_type(2))) _Float16;
 
 constexpr int CK16 = 16;  // input channels per K-chunk
-constexpr int TK = 3;     // taps per weight piece in LDS
+constexpr int TK_MAX = 3;  // taps per weight piece in LDS (template parameter TK <= this)
 
 // sin^2(t) for moderate |t| (snake activations): Cody-Waite reduction to |r| <= pi/4 by multiples of
 // pi/2, even Taylor series of sin^2 on the reduced argument, complement on odd quadrants.
@@ -70,8 +70,8 @@ __device__ __forceinline__ void glds16(const uint4* gsrc_lane, uint4* lds_wave_b
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int ACT>
-__global__ __launch_bounds__(256, 2) void conv1d_f16x3_kernel(const ConvArgs a) {
+template <int BM, int BN, int WM, int WN, int ACT, int TK, bool PF>
+__global__ __launch_bounds__(256, (BM / WM / 32) * (BN / WN / 32) > 4 ? 2 : 3) void conv1d_f16x3_kernel(const ConvArgs a) {
     constexpr int MT = BM / WM / 32;
     constexpr int NT = BN / WN / 32;
     static_assert(WM * WN == 4 && MT >= 1 && NT >= 1, "4 waves per workgroup");
@@ -128,15 +128,33 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_kernel(const ConvArgs a) 
         for (int sgm = wave; sgm < nseg; sgm += 4) glds16(src + sgm * 64 + lane, dst + sgm * 64);
     };
 
-    issue_piece(0, 0, 0);
-    int cur = 0;
-    for (int ch = 0; ch < n_chunks; ++ch) {
-        // ---- stage + transform + split the input chunk.  Wave w takes channel pairs w and w+4 of the 8
-        // pairs; per-channel AdaIN / snake parameters are wave-uniform, lanes run along time (coalesced),
-        // and each lane writes one packed hi pair and one packed lo pair into the [time][8 ch] image.
+    // ---- input chunk staging.  Wave w takes channel pairs w and w+4 of the chunk's 8 pairs; per-channel
+    // AdaIN / snake parameters are wave-uniform, lanes run along time (coalesced), and each lane writes one
+    // packed hi pair and one packed lo pair into the [time][8 ch] image.  With PF the raw values of the NEXT
+    // chunk are loaded into registers before the MFMA loop of the current one (their latency hides behind
+    // the matrix work) and are transformed + written after it.
+    constexpr int NI = 5;  // PF needs XW <= 64 * NI (the launcher checks)
+    float raw[2][NI][2];
+    auto load_raw = [&](int ch) {
 #pragma unroll
-        for (int half = 0; half < ((a.dbg & 1) ? 0 : 2); ++half) {
-            const int pr = wave + 4 * half;            // pair index 0..7 inside the 16-channel chunk
+        for (int half = 0; half < 2; ++half) {
+            const int cA = ch * CK16 + 2 * (wave + 4 * half), cB = cA + 1;
+            const float* rowA = xb + (long)(cA < a.Cin ? cA : 0) * a.x_ld;
+            const float* rowB = xb + (long)(cB < a.Cin ? cB : 0) * a.x_ld;
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const int p = p0 + lane + 64 * it;
+                int pi = up2 ? (p >> 1) : p;
+                pi = pi < 0 ? 0 : (pi >= Lsrc ? Lsrc - 1 : pi);
+                raw[half][it][0] = rowA[pi];
+                raw[half][it][1] = rowB[pi];
+            }
+        }
+    };
+    auto stage_chunk = [&](int ch, bool from_raw) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int pr = wave + 4 * half;  // pair index 0..7 inside the 16-channel chunk
             const int cA = ch * CK16 + 2 * pr, cB = cA + 1;
             const bool okA = cA < a.Cin, okB = cB < a.Cin;
             const int cAc = okA ? cA : 0, cBc = okB ? cB : 0;  // clamped: loads stay in bounds, result masked
@@ -156,29 +174,62 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_kernel(const ConvArgs a) 
             const int g = pr >> 2, jw = pr & 3;
             unsigned* dst_hi = Xs32 + ((0 * 2 + g) * XWp) * 4 + jw;
             unsigned* dst_lo = Xs32 + ((1 * 2 + g) * XWp) * 4 + jw;
-            for (int u = lane; u < XW; u += 64) {
+            auto emit = [&](int u, float xA, float xB) {
                 const int p = p0 + u;
                 const bool pok = p >= 0 && p < Lin;
-                int pi = up2 ? (p >> 1) : p;
-                pi = pi < 0 ? 0 : (pi >= Lsrc ? Lsrc - 1 : pi);
-                float yA = (rowA[pi] - mA) * sA + hA;
-                float yB = (rowB[pi] - mB) * sB + hB;
-                yA = in_act<ACT>(yA, a.slope, aA, iA);
-                yB = in_act<ACT>(yB, a.slope, aB, iB);
+                float yA = in_act<ACT>((xA - mA) * sA + hA, a.slope, aA, iA);
+                float yB = in_act<ACT>((xB - mB) * sB + hB, a.slope, aB, iB);
                 yA = (pok && okA) ? yA : 0.f;  // zero padding comes after the activation
                 yB = (pok && okB) ? yB : 0.f;
                 unsigned hp, lp;
                 split_pair(yA, yB, hp, lp);
                 dst_hi[u * 4] = hp;
                 dst_lo[u * 4] = lp;
+            };
+            if (PF && from_raw) {
+#pragma unroll
+                for (int it = 0; it < NI; ++it) {
+                    const int u = lane + 64 * it;
+                    if (u < XW) emit(u, raw[half][it][0], raw[half][it][1]);
+                }
+            } else {
+                for (int u = lane; u < XW; u += 64) {
+                    const int p = p0 + u;
+                    int pi = up2 ? (p >> 1) : p;
+                    pi = pi < 0 ? 0 : (pi >= Lsrc ? Lsrc - 1 : pi);
+                    emit(u, rowA[pi], rowB[pi]);
+                }
             }
         }
-        __syncthreads();  // Xs complete; the in-flight weight piece has landed (the barrier drains vmcnt)
+    };
+
+    // Co-resident workgroups of one CU start together and would stay in lockstep (staging with staging,
+    // MFMA with MFMA, epilogue with epilogue).  Delay the second first-round workgroup of every CU once, so
+    // that one block's memory/VALU phases run beside the other's matrix phase; later blocks inherit the offset.
+    if (a.stagger_ticks > 0) {
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const bool delayed = (a.dbg & 16) ? (((lin >> 3) & 1u) != 0u) : (lin >= 256u);
+        if (lin < 512u && delayed) {
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t_start < (unsigned long long)a.stagger_ticks)
+                __builtin_amdgcn_s_sleep(32);
+        }
+    }
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (a.stamps) st0 = __builtin_amdgcn_s_memrealtime();
+    issue_piece(0, 0, 0);
+    if (!(a.dbg & 1)) stage_chunk(0, false);
+    __syncthreads();  // Xs complete; the in-flight weight piece has landed (the barrier drains vmcnt)
+    if (a.stamps) st1 = __builtin_amdgcn_s_memrealtime();
+    int cur = 0;
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const bool more = ch + 1 < n_chunks;
+        if (PF && more && !(a.dbg & 1)) load_raw(ch + 1);
         // ---- taps in pieces of TK: prefetch the next piece while this one feeds the matrix pipe ---
         for (int pc = 0; pc < n_pieces; ++pc) {
             if (pc + 1 < n_pieces)
                 issue_piece(ch, pc + 1, cur ^ 1);
-            else if (ch + 1 < n_chunks)
+            else if (more)
                 issue_piece(ch + 1, 0, cur ^ 1);
             const int tp = pc * TK;
             const int taps = (K - tp) < TK ? (K - tp) : TK;
@@ -210,43 +261,87 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_kernel(const ConvArgs a) 
             __syncthreads();  // everyone is done with Wbuf[cur] (and with Xs after the last piece);
             cur ^= 1;         // the prefetched piece has landed
         }
+        if (more) {
+            if (!(a.dbg & 1)) stage_chunk(ch + 1, true);
+            __syncthreads();
+        }
     }
 
+    if (a.stamps) st2 = __builtin_amdgcn_s_memrealtime();
     // ---- epilogue (conv_epilogue.h); accumulators carry the 2^ws weight scale -----------------------
     if (a.dbg & 8) return;
     conv_store_tile<MT, NT>(a, acc, a.w_unscale, b, ct * BM + wm * (MT * 32), t0 + wn * (NT * 32), r, h, ncols, Lout);
+    if (a.stamps && tid == 0) {  // stamps leave through a buffer of their own that nothing else reads
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        unsigned long long* o = a.stamps + (unsigned long long)lin * 8;
+        o[0] = st0; o[1] = st1; o[2] = st2;
+        __builtin_amdgcn_s_waitcnt(0);
+        o[3] = __builtin_amdgcn_s_memrealtime();
+        o[4] = __builtin_amdgcn_s_getreg(63492);  // HW_REG_HW_ID
+        o[5] = __builtin_amdgcn_s_getreg(63508);  // HW_REG_XCC_ID
+    }
 }
 
-template <int BM, int BN, int WM, int WN, int ACT>
-static void launch_inst16_act(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
-    static bool attr_set = false;
-    auto kern = conv1d_f16x3_kernel<BM, BN, WM, WN, ACT>;
-    if (!attr_set) {
-        KX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024));
-        attr_set = true;
-    }
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+template <int BM, int BN, int WM, int WN, int ACT, int TK, bool PF>
+static void launch_inst16_pf(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
+    static size_t lds_limit = 64 * 1024;  // raise the dynamic-LDS limit only as far as a launch needs
+    auto kern = conv1d_f16x3_kernel<BM, BN, WM, WN, ACT, TK, PF>;
     const int XW = (BN - 1) * a.stride + (a.K - 1) * a.dil + 1;
     const int XWp = (XW + 3) & ~3;
     const size_t lds = 16 * ((size_t)2 * TK * 4 * BM + (size_t)4 * XWp);
     KX_REQUIRE(lds <= 160 * 1024, "conv1d f16x3: LDS tile too large for this k/stride");
+    if (lds > lds_limit) {
+        KX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_limit = lds;
+    }
     dim3 grid((max_cols + BN - 1) / BN, (a.Cout + BM - 1) / BM, B);
     KX_REQUIRE(grid.x > 0 && grid.y > 0 && grid.y < 65536 && B > 0 && B < 65536, "conv1d f16x3: bad grid");
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     KX_HIP(hipGetLastError());
 }
 
-template <int BM, int BN, int WM, int WN>
-static void launch_inst16(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
-    if (a.act == ACT_SNAKE)
-        launch_inst16_act<BM, BN, WM, WN, ACT_SNAKE>(a, B, max_cols, s);
-    else if (a.act == ACT_LEAKY)
-        launch_inst16_act<BM, BN, WM, WN, ACT_LEAKY>(a, B, max_cols, s);
+
+template <int BM, int BN, int WM, int WN, int ACT, int TK>
+static void launch_inst16_act(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
+    static const int pf_env = env_int("KX_PF", 1);
+    const int XW = (BN - 1) * a.stride + (a.K - 1) * a.dil + 1;
+    if (pf_env && XW <= 320)
+        launch_inst16_pf<BM, BN, WM, WN, ACT, TK, true>(a, B, max_cols, s);
     else
-        launch_inst16_act<BM, BN, WM, WN, ACT_NONE>(a, B, max_cols, s);
+        launch_inst16_pf<BM, BN, WM, WN, ACT, TK, false>(a, B, max_cols, s);
 }
 
-int conv16_pick_bn(int BM, int max_cols) { return (BM == 128 && max_cols <= 160) ? 128 : 256; }
+template <int BM, int BN, int WM, int WN, int TK>
+static void launch_inst16_tk(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
+    if (a.act == ACT_SNAKE)
+        launch_inst16_act<BM, BN, WM, WN, ACT_SNAKE, TK>(a, B, max_cols, s);
+    else if (a.act == ACT_LEAKY)
+        launch_inst16_act<BM, BN, WM, WN, ACT_LEAKY, TK>(a, B, max_cols, s);
+    else
+        launch_inst16_act<BM, BN, WM, WN, ACT_NONE, TK>(a, B, max_cols, s);
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_inst16(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
+    static const int tk = env_int("KX_TK", 3);
+    if (tk == 1)
+        launch_inst16_tk<BM, BN, WM, WN, 1>(a, B, max_cols, s);
+    else if (tk == 2)
+        launch_inst16_tk<BM, BN, WM, WN, 2>(a, B, max_cols, s);
+    else
+        launch_inst16_tk<BM, BN, WM, WN, 3>(a, B, max_cols, s);
+}
+
+int conv16_pick_bn(int BM, int max_cols) {
+    static const int force = env_int("KX_BN", 0);
+    if (BM == 128 && force == 128) return 128;
+    return (BM == 128 && max_cols <= 160) ? 128 : 256;
+}
 
 void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStream_t s) {
     KX_REQUIRE(a.n_chunks16 == (a.Cin + CK16 - 1) / CK16 && a.w16 != nullptr, "conv1d f16x3: weights not packed");

@@ -386,8 +386,25 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     a.w_unscale = w.unscale;
     static const int dbg_env = getenv("KX_DBG") ? atoi(getenv("KX_DBG")) : 0;
     a.dbg = dbg_env;
+    {
+        // matrix-pipe time of one 128 x 256 workgroup tile in microseconds (3 MFMAs of 32 cycles per 32x32x16 block)
+        static const double stag_env = getenv("KX_STAGGER") ? atof(getenv("KX_STAGGER")) : 0.0;
+        const double mfma_cycles = 4.0 * 8.0 * ((w.Cin + 15) / 16) * w.K * 3.0 * 32.0 / 4.0;
+        a.stagger_ticks = (int)(stag_env * mfma_cycles / 2400.0 * 100.0);
+    }
     const bool f16 = conv_mode == CONV_F16X3;
     const int max_cols = (o.store == ST_UPSCATTER) ? in.Lmax + 1 : out.Lmax;
+    // diagnostic: KX_STAMP=<file> dumps per-workgroup timestamps of the first 128->128 k=11 launch
+    static const char* stamp_path = getenv("KX_STAMP");
+    static bool stamped = false;
+    unsigned long long* d_stamps = nullptr;
+    long n_wg = 0;
+    if (stamp_path && !stamped && f16 && w.K == 11 && w.rows == 128 && B_ >= 8) {
+        n_wg = (long)((max_cols + 255) / 256) * B_;
+        KX_HIP(hipMalloc((void**)&d_stamps, n_wg * 64));
+        KX_HIP(hipMemsetAsync(d_stamps, 0, n_wg * 64, stream_));
+        a.stamps = d_stamps;
+    }
     if (prof_on_ && w.BM == 128) {  // the dominant instantiation conv1d_mfma_kernel<128,128,2,2>
         const LenMap& lm = (o.store == ST_UPSCATTER) ? in.len : out.len;
         const std::vector<int>& hl = (lm.lens == dT_) ? hT_ : hF_;
@@ -411,6 +428,17 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     } else {
         if (f16) launch_conv1d_f16x3(a, w.BM, B_, max_cols, stream_);
         else launch_conv1d(a, w.BM, B_, max_cols, stream_);
+    }
+    if (d_stamps) {
+        stamped = true;
+        KX_HIP(hipStreamSynchronize(stream_));
+        std::vector<unsigned long long> hst(n_wg * 8);
+        KX_HIP(hipMemcpy(hst.data(), d_stamps, n_wg * 64, hipMemcpyDeviceToHost));
+        KX_HIP(hipFree(d_stamps));
+        if (FILE* f = fopen(stamp_path, "wb")) {
+            fwrite(hst.data(), 8, hst.size(), f);
+            fclose(f);
+        }
     }
 }
 
