@@ -139,7 +139,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--phonemes", type=int, default=128)
-    ap.add_argument("--cpu-utts", type=int, default=3, help="utterances in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-utts", type=int, default=12, help="utterances in the CPU baseline sample (0 = skip)")
     ap.add_argument("--detail", default="", help="write a per-shape table of the conv launches to this file")
     ap.add_argument("--free-run", type=int, default=1, help="also time one step with predicted durations")
     a = ap.parse_args()

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, (BM / WM / 32) * (BN / WN / 32) > 4 ? 2 : 3) v
                 __builtin_amdgcn_s_sleep(32);
         }
     }
-    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, acc_stage = 0, acc_bar = 0;
     if (a.stamps) st0 = __builtin_amdgcn_s_memrealtime();
     issue_piece(0, 0, 0);
     if (!(a.dbg & 1)) stage_chunk(0, false);
@@ -262,8 +262,15 @@ __global__ __launch_bounds__(256, (BM / WM / 32) * (BN / WN / 32) > 4 ? 2 : 3) v
             cur ^= 1;         // the prefetched piece has landed
         }
         if (more) {
+            unsigned long long ta = 0, tb = 0;
+            if (a.stamps) ta = __builtin_amdgcn_s_memrealtime();
             if (!(a.dbg & 1)) stage_chunk(ch + 1, true);
+            if (a.stamps) tb = __builtin_amdgcn_s_memrealtime();
             __syncthreads();
+            if (a.stamps) {
+                acc_stage += tb - ta;
+                acc_bar += __builtin_amdgcn_s_memrealtime() - tb;
+            }
         }
     }
 
@@ -279,6 +286,8 @@ __global__ __launch_bounds__(256, (BM / WM / 32) * (BN / WN / 32) > 4 ? 2 : 3) v
         o[3] = __builtin_amdgcn_s_memrealtime();
         o[4] = __builtin_amdgcn_s_getreg(63492);  // HW_REG_HW_ID
         o[5] = __builtin_amdgcn_s_getreg(63508);  // HW_REG_XCC_ID
+        o[6] = acc_stage;
+        o[7] = acc_bar;
     }
 }
 

@@ -173,10 +173,92 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* qkv, long b
         __builtin_amdgcn_wave_barrier();
     }
 }
+// LDS form for T <= 256: K [64][Tp] and V^T [T][65] of the head are staged once per workgroup, so the
+// score and P.V loops read only LDS (lane-contiguous, conflict-free) instead of re-streaming K/V from L2
+// for every query row.
+__global__ __launch_bounds__(256) void attention_lds_kernel(const float* qkv, long bs, int ld, float* ctx, long cbs,
+                                                            int cld, const int* lens) {
+    extern __shared__ __attribute__((aligned(16))) float att_smem[];
+    const int b = blockIdx.x, hd = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int T = lens[b];
+    const int Tp = (T + 3) & ~3;
+    float* Ks = att_smem;               // [64][Tp]
+    float* Vt = Ks + 64 * Tp;           // [T][65]
+    float* ps = Vt + T * 65;            // [4][Tp]
+    float* qs = ps + 4 * Tp;            // [4][64]
+    const float* Q = qkv + b * bs + (long)(hd * 64) * ld;
+    const float* Kp = Q + (long)768 * ld;
+    const float* V = Q + (long)1536 * ld;
+    for (int idx = threadIdx.x; idx < 64 * T; idx += 256) {
+        const int d = idx / T, j = idx - d * T;
+        Ks[d * Tp + j] = Kp[(long)d * ld + j];
+        Vt[j * 65 + d] = V[(long)d * ld + j];
+    }
+    __syncthreads();
+    const int nslot = (T + 63) >> 6;  // <= 4
+    float* pw = ps + wave * Tp;
+    float* qw = qs + wave * 64;
+    for (int i = wave; i < T; i += 4) {
+        qw[lane] = Q[(long)lane * ld + i];
+        __builtin_amdgcn_wave_barrier();
+        float sc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int d = 0; d < 64; ++d) {
+            const float qd = qw[d];
+            const float* kr = Ks + d * Tp;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int j = lane + 64 * m;
+                if (m < nslot && j < T) sc[m] += qd * kr[j];
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int j = lane + 64 * m;
+            sc[m] = (m < nslot && j < T) ? sc[m] * 0.125f : -INFINITY;
+            mx = fmaxf(mx, sc[m]);
+        }
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int j = lane + 64 * m;
+            if (m < nslot && j < T) {
+                sc[m] = expf(sc[m] - mx);
+                sum += sc[m];
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int j = lane + 64 * m;
+            if (m < nslot && j < T) pw[j] = sc[m] / sum;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float o = 0.f;
+        for (int j = 0; j < T; ++j) o += pw[j] * Vt[j * 65 + lane];
+        ctx[b * cbs + (long)(hd * 64 + lane) * cld + i] = o;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 void launch_attention(const float* qkv, long bs, int ld, float* ctx, long cbs, int cld, const int* lens, int B,
                       int Tmax, hipStream_t s) {
     KX_REQUIRE(Tmax <= 512, "attention: T > 512");
-    hipLaunchKernelGGL(attention_kernel, dim3(B, 12), dim3(256), 0, s, qkv, bs, ld, ctx, cbs, cld, lens);
+    if (Tmax <= 256) {
+        const int Tp = (Tmax + 3) & ~3;
+        const size_t lds = sizeof(float) * ((size_t)64 * Tp + (size_t)Tmax * 65 + 4 * Tp + 4 * 64);
+        static size_t lds_limit = 64 * 1024;
+        if (lds > lds_limit) {
+            KX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_lds_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_limit = lds;
+        }
+        hipLaunchKernelGGL(attention_lds_kernel, dim3(B, 12), dim3(256), lds, s, qkv, bs, ld, ctx, cbs, cld, lens);
+    } else {
+        hipLaunchKernelGGL(attention_kernel, dim3(B, 12), dim3(256), 0, s, qkv, bs, ld, ctx, cbs, cld, lens);
+    }
     KX_HIP(hipGetLastError());
 }
 

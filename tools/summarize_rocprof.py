@@ -28,11 +28,14 @@ def main(prof_dir, bench_json, out):
                   f"#   roofline kernel {r['kernel']}",
                   f"#   avg launch {r['avg_launch_ms'] * 1e3:.1f} us over {r['launches_per_step']:.0f} launches/step, "
                   f"{r['gflop_per_launch']:.1f} GFLOP/launch -> {r['achieved']:.1f} TFLOP/s = {r['frac'] * 100:.1f}% of "
-                  f"{r['peak']} TFLOP/s (f32 MFMA dense peak)"]
-        k = [x for x in rows if "conv1d_mfma_kernel<128, 128, 2, 2>" in x["Name"]]
-        if k:
-            lines.append(f"#   rocprof average for the same kernel: {float(k[0]['AverageNs']) / 1e3:.1f} us "
-                         f"({k[0]['Calls']} calls incl. warm-up)")
+                  f"{r['peak']} TFLOP/s (dense MFMA peak of the kernel's dtype)"]
+        fam = [x for x in rows if "conv1d_mfma_kernel<128, 128, 2, 2>" in x["Name"]
+               or "conv1d_f16x3_kernel<128," in x["Name"]]
+        if fam:
+            calls = sum(int(x["Calls"]) for x in fam)
+            tot_ns = sum(float(x["TotalDurationNs"]) for x in fam)
+            lines.append(f"#   rocprof average over the same kernel family: {tot_ns / calls / 1e3:.1f} us "
+                         f"({calls} calls incl. warm-up)")
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
