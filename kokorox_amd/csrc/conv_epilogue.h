@@ -14,26 +14,50 @@ __device__ __forceinline__ float gelu_new_f(float x) {
     return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * (x * x * x))));
 }
 
+// x + (x moved by a DPP lane pattern): full-rate VALU, no LDS crossbar
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+    const int moved = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true);
+    return x + __builtin_bit_cast(float, moved);
+}
+// sum over the 32 lanes of a half-wave, result in every lane: xor-1, xor-2 (quad_perm), half-mirror and
+// mirror inside each row of 16, then one cross-row exchange
+__device__ __forceinline__ float half_wave_sum(float x) {
+    x = dpp_add<0xB1>(x);   // quad_perm [1,0,3,2]
+    x = dpp_add<0x4E>(x);   // quad_perm [2,3,0,1]
+    x = dpp_add<0x141>(x);  // row_half_mirror
+    x = dpp_add<0x140>(x);  // row_mirror
+    return x + __shfl_xor(x, 16);
+}
+
 // acc scale: the f16x3 path carries the 2^ws weight pre-scale in its accumulators
 template <int MT, int NT>
 __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)[MT][NT], float acc_scale, int b,
-                                                int row0, int col0, int r, int h, int ncols, int Lout) {
-    if (a.store == ST_NORMAL) {
+                                                int row0, int col0, int r, int h, int ncols, int Lout, int stat_slot) {
+    if (a.store == ST_NORMAL || a.store == ST_TMAJOR) {
         // Latency-bound read-modify-write of the tile: issue the residual / accumulate loads of 8 rows x NT
         // columns back to back (addresses clamped so the loads need no branches), then combine and store.
-        const bool has_res = a.resid != nullptr, has_bias = a.bias != nullptr;
-        const bool accum = a.accum != 0, gelu = a.epi == EPI_GELU_NEW, do_div = a.out_div != 1.0f;
-        float* yb = a.y + (long)b * a.y_bs;
-        const float* rb = has_res ? a.resid + (long)b * a.r_bs : yb;
+        const bool tmaj = a.store == ST_TMAJOR;
+        const bool has_res = a.resid != nullptr && !tmaj, has_bias = a.bias != nullptr;
+        const bool accum = a.accum != 0 && !tmaj, gelu = a.epi == EPI_GELU_NEW, do_div = a.out_div != 1.0f;
         const int cmax = ncols - 1, rmax = a.Cout - 1;
-        int colc[NT];
+        // per-column element offsets (without the row term); merged mode maps column -> (utterance, t)
+        long ycol[NT], rcol[NT];
         bool cok[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = col0 + nt * 32 + r;
             cok[nt] = col < ncols;
-            colc[nt] = col < cmax ? col : cmax;
+            const int cc = col < cmax ? col : cmax;
+            int bb = b, tt = cc;
+            if (a.merge_T > 0) {
+                bb = cc / a.merge_T;
+                tt = cc - bb * a.merge_T;
+            }
+            ycol[nt] = (long)bb * a.y_bs + (tmaj ? (long)tt * a.y_ld : (long)tt);
+            rcol[nt] = (long)bb * a.r_bs + tt;
         }
+        const long yrs = tmaj ? 1 : a.y_ld;  // row stride of the output
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -47,17 +71,20 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)
                     const int row = row0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     rok[e8] = row < a.Cout;
                     const int rowc = row < rmax ? row : rmax;
-                    yo[e8] = (long)rowc * a.y_ld;
+                    yo[e8] = (long)rowc * yrs;
                     bv[e8] = has_bias ? a.bias[rowc] : 0.f;
-                    const long ro = (long)rowc * (has_res ? a.r_ld : a.y_ld);
+                    const long ro = (long)rowc * a.r_ld;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        rv[e8][nt] = has_res ? rb[ro + colc[nt]] : 0.f;
-                        yv[e8][nt] = accum ? yb[yo[e8] + colc[nt]] : 0.f;
+                        rv[e8][nt] = has_res ? a.resid[ro + rcol[nt]] : 0.f;
+                        yv[e8][nt] = accum ? a.y[yo[e8] + ycol[nt]] : 0.f;
                     }
                 }
+                float rs[8], rq[8];
 #pragma unroll
                 for (int e8 = 0; e8 < 8; ++e8) {
+                    rs[e8] = 0.f;
+                    rq[e8] = 0.f;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         float v = acc[mt][nt][eg * 8 + e8] * acc_scale + bv[e8];
@@ -66,27 +93,24 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)
                         v *= a.out_mul;
                         if (do_div) v = v / a.out_div;
                         if (gelu) v = gelu_new_f(v);
-                        if (rok[e8] && cok[nt]) yb[yo[e8] + colc[nt]] = v;
+                        if (rok[e8] && cok[nt]) a.y[yo[e8] + ycol[nt]] = v;
+                        const float vm = cok[nt] ? v : 0.f;
+                        rs[e8] += vm;
+                        rq[e8] += vm * vm;
                     }
                 }
-            }
-        }
-        return;
-    }
-    if (a.store == ST_TMAJOR) {  // [B][L][y_ld]: LSTM gate pre-activations (bias only)
-        float* yb = a.y + (long)b * a.y_bs;
+                if (a.stat_part) {
+                    // fused InstanceNorm statistics of what was just stored: reduce each row's partial over the
+                    // 32 lanes of this half-wave (lanes = columns), one (sum, sumsq) per row and column slot
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = row0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row >= a.Cout) continue;
-                const float bv = a.bias ? a.bias[row] : 0.f;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int col = col0 + nt * 32 + r;
-                    if (col >= ncols) continue;
-                    yb[(long)col * a.y_ld + row] = (acc[mt][nt][e] * acc_scale + bv) * a.out_mul;
+                    for (int e8 = 0; e8 < 8; ++e8) {
+                        const float sv = half_wave_sum(rs[e8]), qv = half_wave_sum(rq[e8]);
+                        if (r == 0 && rok[e8]) {
+                            const int e = eg * 8 + e8;
+                            const int row = row0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            a.stat_part[((long)b * a.Cout + row) * a.stat_tiles + stat_slot] = make_float2(sv, qv);
+                        }
+                    }
                 }
             }
         }

@@ -84,9 +84,10 @@ __global__ __launch_bounds__(256, (BM / WM / 32) * (BN / WN / 32) > 4 ? 2 : 3) v
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, ct = blockIdx.y;
     const int t0 = blockIdx.x * BN;
+    const bool merged = a.merge_T > 0;
 
-    const int Lin = a.in_len.lens[b] * a.in_len.mul + a.in_len.add;
-    const int Lout = a.out_len.lens[b] * a.out_len.mul + a.out_len.add;
+    const int Lin = merged ? a.merge_B * a.merge_T : a.in_len.lens[b] * a.in_len.mul + a.in_len.add;
+    const int Lout = merged ? Lin : a.out_len.lens[b] * a.out_len.mul + a.out_len.add;
     const int ncols = (a.store == ST_UPSCATTER) ? (Lin + 1) : Lout;
     if (t0 >= ncols) return;
 
@@ -135,19 +136,38 @@ __global__ __launch_bounds__(256, (BM / WM / 32) * (BN / WN / 32) > 4 ? 2 : 3) v
     // the matrix work) and are transformed + written after it.
     constexpr int NI = 5;  // PF needs XW <= 64 * NI (the launcher checks)
     float raw[2][NI][2];
+    // per-lane element offsets of this lane's NI window columns (they do not depend on the chunk)
+    long xoff[NI];
+    unsigned okmask = 0;
+    if (PF) {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int p = p0 + lane + 64 * it;
+            if (merged) {
+                const int pc = p < Lin ? p : Lin - 1;
+                const int bb = pc / a.merge_T, tt = pc - bb * a.merge_T;
+                const bool ok = p < Lin && tt < a.in_len.lens[bb];
+                okmask |= ok ? (1u << it) : 0u;
+                xoff[it] = (long)bb * a.x_bs + tt;
+            } else {
+                okmask |= (p >= 0 && p < Lin) ? (1u << it) : 0u;
+                int pi = up2 ? (p >> 1) : p;
+                pi = pi < 0 ? 0 : (pi >= Lsrc ? Lsrc - 1 : pi);
+                xoff[it] = pi;
+            }
+        }
+    }
+    const float* xbase = merged ? a.x : xb;
     auto load_raw = [&](int ch) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int cA = ch * CK16 + 2 * (wave + 4 * half), cB = cA + 1;
-            const float* rowA = xb + (long)(cA < a.Cin ? cA : 0) * a.x_ld;
-            const float* rowB = xb + (long)(cB < a.Cin ? cB : 0) * a.x_ld;
+            const float* rowA = xbase + (long)(cA < a.Cin ? cA : 0) * a.x_ld;
+            const float* rowB = xbase + (long)(cB < a.Cin ? cB : 0) * a.x_ld;
 #pragma unroll
             for (int it = 0; it < NI; ++it) {
-                const int p = p0 + lane + 64 * it;
-                int pi = up2 ? (p >> 1) : p;
-                pi = pi < 0 ? 0 : (pi >= Lsrc ? Lsrc - 1 : pi);
-                raw[half][it][0] = rowA[pi];
-                raw[half][it][1] = rowB[pi];
+                raw[half][it][0] = rowA[xoff[it]];
+                raw[half][it][1] = rowB[xoff[it]];
             }
         }
     };
@@ -168,15 +188,13 @@ __global__ __launch_bounds__(256, (BM / WM / 32) * (BN / WN / 32) > 4 ? 2 : 3) v
                 aA = a.alpha[cAc]; iA = 1.0f / aA;
                 aB = a.alpha[cBc]; iB = 1.0f / aB;
             }
-            const float* rowA = xb + (long)cAc * a.x_ld;
-            const float* rowB = xb + (long)cBc * a.x_ld;
+            const float* rowA = xbase + (long)cAc * a.x_ld;
+            const float* rowB = xbase + (long)cBc * a.x_ld;
             // dword index of (hi image, octet g, column 0, channel slot j): ((0*2+g)*XWp)*4 + j/2
             const int g = pr >> 2, jw = pr & 3;
             unsigned* dst_hi = Xs32 + ((0 * 2 + g) * XWp) * 4 + jw;
             unsigned* dst_lo = Xs32 + ((1 * 2 + g) * XWp) * 4 + jw;
-            auto emit = [&](int u, float xA, float xB) {
-                const int p = p0 + u;
-                const bool pok = p >= 0 && p < Lin;
+            auto emit = [&](int u, float xA, float xB, bool pok) {
                 float yA = in_act<ACT>((xA - mA) * sA + hA, a.slope, aA, iA);
                 float yB = in_act<ACT>((xB - mB) * sB + hB, a.slope, aB, iB);
                 yA = (pok && okA) ? yA : 0.f;  // zero padding comes after the activation
@@ -190,14 +208,22 @@ __global__ __launch_bounds__(256, (BM / WM / 32) * (BN / WN / 32) > 4 ? 2 : 3) v
 #pragma unroll
                 for (int it = 0; it < NI; ++it) {
                     const int u = lane + 64 * it;
-                    if (u < XW) emit(u, raw[half][it][0], raw[half][it][1]);
+                    if (u < XW) emit(u, raw[half][it][0], raw[half][it][1], ((okmask >> it) & 1u) != 0u);
                 }
             } else {
-                for (int u = lane; u < XW; u += 64) {
-                    const int p = p0 + u;
-                    int pi = up2 ? (p >> 1) : p;
-                    pi = pi < 0 ? 0 : (pi >= Lsrc ? Lsrc - 1 : pi);
-                    emit(u, rowA[pi], rowB[pi]);
+                if (PF) {  // first chunk of the prefetching build: same hoisted offsets, loads issued here
+#pragma unroll
+                    for (int it = 0; it < NI; ++it) {
+                        const int u = lane + 64 * it;
+                        if (u < XW) emit(u, rowA[xoff[it]], rowB[xoff[it]], ((okmask >> it) & 1u) != 0u);
+                    }
+                } else {
+                    for (int u = lane; u < XW; u += 64) {
+                        const int p = p0 + u;
+                        int pi = up2 ? (p >> 1) : p;
+                        pi = pi < 0 ? 0 : (pi >= Lsrc ? Lsrc - 1 : pi);
+                        emit(u, rowA[pi], rowB[pi], p >= 0 && p < Lin);
+                    }
                 }
             }
         }
@@ -277,7 +303,8 @@ __global__ __launch_bounds__(256, (BM / WM / 32) * (BN / WN / 32) > 4 ? 2 : 3) v
     if (a.stamps) st2 = __builtin_amdgcn_s_memrealtime();
     // ---- epilogue (conv_epilogue.h); accumulators carry the 2^ws weight scale -----------------------
     if (a.dbg & 8) return;
-    conv_store_tile<MT, NT>(a, acc, a.w_unscale, b, ct * BM + wm * (MT * 32), t0 + wn * (NT * 32), r, h, ncols, Lout);
+    conv_store_tile<MT, NT>(a, acc, a.w_unscale, b, ct * BM + wm * (MT * 32), t0 + wn * (NT * 32), r, h, ncols, Lout,
+                            blockIdx.x * WN + wn);
     if (a.stamps && tid == 0) {  // stamps leave through a buffer of their own that nothing else reads
         const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         unsigned long long* o = a.stamps + (unsigned long long)lin * 8;
@@ -308,8 +335,11 @@ static void launch_inst16_pf(const ConvArgs& a, int B, int max_cols, hipStream_t
         KX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_limit = lds;
     }
-    dim3 grid((max_cols + BN - 1) / BN, (a.Cout + BM - 1) / BM, B);
+    dim3 grid((max_cols + BN - 1) / BN, (a.Cout + BM - 1) / BM, a.merge_T > 0 ? 1 : B);
     KX_REQUIRE(grid.x > 0 && grid.y > 0 && grid.y < 65536 && B > 0 && B < 65536, "conv1d f16x3: bad grid");
+    KX_REQUIRE(a.merge_T == 0 || (PF && a.K == 1 && a.stride == 1 && a.pad == 0 && !a.in_up2 && !a.nmean &&
+                                  a.store != ST_UPSCATTER && !a.stat_part),
+               "conv1d f16x3: merged columns need a plain k=1 GEMM");
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     KX_HIP(hipGetLastError());
 }

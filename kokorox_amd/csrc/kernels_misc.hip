@@ -330,6 +330,42 @@ void launch_in_stats(const float* x, long bs, int ld, int C, LenMap len, int B, 
     KX_HIP(hipGetLastError());
 }
 
+// fused form: the producing conv's epilogue left per-tile partial sums (conv_epilogue.h)
+__global__ __launch_bounds__(64) void stats_finalize_kernel(const float2* part, int tiles, int cols_per_tile, int C,
+                                                            LenMap len, const float* gb, long gb_bs, float* mean,
+                                                            float* scale, float* shift, int n_bs) {
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int L = len_of(len, b);
+    const int used = ((L + cols_per_tile - 1) / cols_per_tile);  // slots written by workgroups that did not exit early
+    const float2* p = part + ((long)b * C + c) * tiles;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < used && i < tiles; i += 64) {
+        const float2 v = p[i];
+        s += (double)v.x;
+        q += (double)v.y;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o);
+        q += __shfl_down(q, o);
+    }
+    if (threadIdx.x == 0) {
+        const double m = L > 0 ? s / L : 0.0;
+        double var = L > 0 ? q / L - m * m : 0.0;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+        const float g = gb[b * gb_bs + c], be = gb[b * gb_bs + C + c];
+        mean[(long)b * n_bs + c] = (float)m;
+        scale[(long)b * n_bs + c] = (1.0f + g) * rstd;
+        shift[(long)b * n_bs + c] = be;
+    }
+}
+void launch_stats_finalize(const float2* part, int tiles, int cols_per_tile, int C, LenMap len, int B, const float* gb,
+                           long gb_bs, float* mean, float* scale, float* shift, int n_bs, hipStream_t s) {
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(C, B), dim3(64), 0, s, part, tiles, cols_per_tile, C, len, gb, gb_bs,
+                       mean, scale, shift, n_bs);
+    KX_HIP(hipGetLastError());
+}
+
 // ---- row fills / copies ---------------------------------------------------------------------
 __global__ void fill_style_rows_kernel(float* dst, long bs, int ld, int row0, const float* styles, int style_off,
                                        const int* lens) {

@@ -82,6 +82,12 @@ struct ConvArgs {
     const void* w16;
     int n_chunks16;
     float w_unscale;
+    // k = 1 GEMMs over a short axis: columns of all B utterances form one merged space of B * merge_T
+    // columns (utterance = col / merge_T); 0 = off.  Requires K = 1, stride 1, pad 0, no norm, no in_up2.
+    int merge_T;
+    int merge_B;
+    float2* stat_part;  // optional [B][Cout][stat_tiles] partial (sum, sum of squares) of the stored values
+    int stat_tiles;
     int stagger_ticks;  // first-round stagger of co-resident workgroups, in 100 MHz ticks (0 = off)
     unsigned long long* stamps;  // diagnostic build only: per-workgroup {t0,t1,t2,t3,hw_id,xcc_id,0,0}
     int dbg;  // timing ablations (env KX_DBG): 1 skip input staging, 2 skip weight copies, 4 skip MFMA, 8 skip epilogue
@@ -108,6 +114,7 @@ size_t packed_conv_floats(int rows, int Cin, int K, int BM);
 // f16x3 split path
 enum ConvMode { CONV_F32 = 0, CONV_F16X3 = 1 };
 void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStream_t s);
+int conv16_pick_bn(int BM, int max_cols);
 size_t packed_conv16_halves(int rows, int Cin, int K, int BM);
 float device_absmax(const float* p, long n, hipStream_t s);
 int pick_weight_shift(float absmax);
@@ -144,6 +151,9 @@ void launch_style_fc(const FcDesc* d_desc, int n_desc, const float* styles, floa
                      hipStream_t s);
 
 // instance-norm statistics of [B][C][ld] rows -> mean, scale = rstd*(1+gamma), shift = beta
+// finalize fused statistics: partials [B][C][tiles] -> mean, scale, shift (same outputs as launch_in_stats)
+void launch_stats_finalize(const float2* part, int tiles, int cols_per_tile, int C, LenMap len, int B, const float* gb,
+                           long gb_bs, float* mean, float* scale, float* shift, int n_bs, hipStream_t s);
 void launch_in_stats(const float* x, long bs, int ld, int C, LenMap len, int B, const float* gb, long gb_bs,
                      float* mean, float* scale, float* shift, int n_bs, hipStream_t s);
 

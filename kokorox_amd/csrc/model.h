@@ -83,6 +83,7 @@ struct ConvOpts {
     int store = ST_NORMAL;
     int up_pad = 0, up_off = 0, up_reflect = 0;
     LenMap up_len{nullptr, 1, 0};  // ST_UPSCATTER: un-shifted output length
+    float2* stat_part = nullptr;   // fuse InstanceNorm partial sums of the output into the epilogue
 };
 
 class Model {
@@ -131,7 +132,7 @@ class Model {
     void adain_resblk(const std::string& name, const T& x, const T& out, bool upsample, float* ws_a, float* ws_b,
                       float* ws_c);
     void adain_resblock1(const std::string& name, int k, const T& x, const T& xj, const T& t1, const T& out,
-                         int accum, float out_div);
+                         int accum, float out_div, float2* part_t1, float2* part_xj);
     void lstm(const LstmW& w, const T& in, const T& out, float* gx);
     void tap(const char* name, const T& t);
     void ensure_arena(Arena& a, size_t bytes);
@@ -162,6 +163,9 @@ class Model {
     bool taps_on_ = false;
     bool dry_ = false;  // sizing pass: allocate (count) but launch nothing
     std::map<std::string, Tap> taps_;
+
+    struct PartInfo { const float2* part; int tiles, cols_per_tile, C; };
+    std::map<const float*, PartInfo> parts_;  // output tensor -> fused statistics partials of its producer
 
     bool prof_on_ = false;
     std::vector<hipEvent_t> ev_;

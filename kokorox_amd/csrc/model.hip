@@ -381,9 +381,26 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     a.up_off = o.up_off;
     a.up_reflect = o.up_reflect;
     a.up_cout = w.up_cout ? w.up_cout : 1;
+    const bool f16 = conv_mode == CONV_F16X3;
     a.w16 = w.w16;
     a.n_chunks16 = w.n_chunks16;
     a.w_unscale = w.unscale;
+    parts_.erase(out.p);  // whatever statistics were known for this tensor are stale now
+    static const bool fuse_stats = !(getenv("KX_FUSE_STATS") && atoi(getenv("KX_FUSE_STATS")) == 0);
+    if (fuse_stats && o.stat_part && o.store == ST_NORMAL && !o.accum) {
+        const int max_c = out.Lmax;
+        int bn, wn;
+        if (conv_mode == CONV_F16X3) {
+            bn = conv16_pick_bn(w.BM, max_c);
+            wn = w.BM == 128 ? 2 : 4;
+        } else {
+            bn = conv_bn(w.BM);
+            wn = w.BM == 128 ? 2 : 4;
+        }
+        a.stat_part = o.stat_part;
+        a.stat_tiles = ((max_c + bn - 1) / bn) * wn;
+        parts_[out.p] = PartInfo{o.stat_part, a.stat_tiles, bn / wn, w.rows};
+    }
     static const int dbg_env = getenv("KX_DBG") ? atoi(getenv("KX_DBG")) : 0;
     a.dbg = dbg_env;
     {
@@ -392,8 +409,15 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
         const double mfma_cycles = 4.0 * 8.0 * ((w.Cin + 15) / 16) * w.K * 3.0 * 32.0 / 4.0;
         a.stagger_ticks = (int)(stag_env * mfma_cycles / 2400.0 * 100.0);
     }
-    const bool f16 = conv_mode == CONV_F16X3;
-    const int max_cols = (o.store == ST_UPSCATTER) ? in.Lmax + 1 : out.Lmax;
+    int max_cols = (o.store == ST_UPSCATTER) ? in.Lmax + 1 : out.Lmax;
+    static const bool merge_env = !(getenv("KX_MERGE") && atoi(getenv("KX_MERGE")) == 0);
+    if (merge_env && f16 && B_ > 1 && w.K == 1 && o.stride == 1 && o.pad == 0 && !o.in_up2 && !o.nmean &&
+        o.store != ST_UPSCATTER && !o.stat_part && in.Lmax <= 512 && in.len.mul == 1 && in.len.add == 0 &&
+        out.len.lens == in.len.lens && out.len.mul == 1 && out.len.add == 0) {
+        a.merge_T = in.Lmax;  // k = 1 GEMM on a short axis: one merged column space for the whole batch
+        a.merge_B = B_;
+        max_cols = B_ * in.Lmax;
+    }
     // diagnostic: KX_STAMP=<file> dumps per-workgroup timestamps of the first 128->128 k=11 launch
     static const char* stamp_path = getenv("KX_STAMP");
     static bool stamped = false;
@@ -444,6 +468,13 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
 
 void Model::stats(const T& x, const std::string& fc_key) {
     if (dry_) return;
+    auto it = parts_.find(x.p);
+    if (it != parts_.end() && it->second.C == x.C) {
+        const PartInfo& pi = it->second;
+        launch_stats_finalize(pi.part, pi.tiles, pi.cols_per_tile, x.C, x.len, B_, gb_ + fc_off(fc_key), gb_total_,
+                              nmean_, nscale_, nshift_, n_bs_, stream_);
+        return;
+    }
     launch_in_stats(x.p, x.bs, x.ld, x.C, x.len, B_, gb_ + fc_off(fc_key), gb_total_, nmean_, nscale_, nshift_, n_bs_,
                     stream_);
 }
@@ -535,7 +566,7 @@ void Model::adain_resblk(const std::string& name, const T& x, const T& out, bool
 // AdaINResBlock1 with Snake1D (istftnet.py).  x is read-only; xj/t1 are scratch of x's shape;
 // the third iteration lands in `out` (optionally accumulated and divided: mean over kernels).
 void Model::adain_resblock1(const std::string& name, int k, const T& x, const T& xj, const T& t1, const T& out,
-                            int accum, float out_div) {
+                            int accum, float out_div, float2* part_t1, float2* part_xj) {
     static const int dils[3] = {1, 3, 5};
     for (int i = 0; i < 3; ++i) {
         const std::string s = std::to_string(i);
@@ -548,6 +579,7 @@ void Model::adain_resblock1(const std::string& name, int k, const T& x, const T&
         o1.alpha = dry_ ? nullptr : wt(name + ".alpha1." + s);
         o1.dil = dils[i];
         o1.pad = (k * dils[i] - dils[i]) / 2;
+        o1.stat_part = part_t1;  // t1 is normalised by adain2 next
         conv(convs_.at(name + ".convs1." + s), cur, t1, o1);
         stats(t1, name + ".adain2." + s);
         ConvOpts o2;
@@ -559,6 +591,8 @@ void Model::adain_resblock1(const std::string& name, int k, const T& x, const T&
         if (i == 2) {
             o2.accum = accum;
             o2.out_div = out_div;
+        } else {
+            o2.stat_part = part_xj;  // xj is normalised by the next iteration's adain1
         }
         conv(convs_.at(name + ".convs2." + s), t1, dst, o2);
     }
@@ -632,6 +666,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     Tmax_ = Tmax;
     taps_on_ = (flags & 2u) != 0;
     taps_.clear();
+    parts_.clear();
     hT_.assign(lens_host, lens_host + B);
     hF_.assign(B, 0);
     const int Tp = up4(Tmax);
@@ -863,12 +898,16 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
             const int ch = st == 0 ? 256 : 128;
             auto S = [&](int C) { return st == 0 ? F20(C) : F121(C); };
             T ns = S(ch), xj = S(ch), t1 = S(ch), xu = S(ch), xs = S(ch);
+            const size_t part_n = (size_t)B * ch * ((st == 0 ? 20 * Fmax : 120 * Fmax + 1) / 64 + 4);  // >= tiles * WN
+            float2* part_t1 = static_cast<float2*>(A.alloc(part_n * sizeof(float2)));
+            float2* part_xj = static_cast<float2*>(A.alloc(part_n * sizeof(float2)));
             {
                 ConvOpts o;
                 if (st == 0) { o.stride = 6; o.pad = 3; }
+                o.stat_part = part_xj;
                 conv(convs_.at(G + "noise_convs." + std::to_string(st)), har, ns, o);
             }
-            adain_resblock1(G + "noise_res." + std::to_string(st), st == 0 ? 7 : 11, ns, ns, t1, ns, 0, 1.f);
+            adain_resblock1(G + "noise_res." + std::to_string(st), st == 0 ? 7 : 11, ns, ns, t1, ns, 0, 1.f, part_t1, part_xj);
             tap(("gen.x_source." + std::to_string(st)).c_str(), ns);
             {
                 ConvOpts o;  // x = ups(leaky_relu(x, 0.1)) (+ reflection pad on the last stage) + x_source
@@ -885,7 +924,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
             static const int ks[3] = {3, 7, 11};
             for (int j = 0; j < 3; ++j)
                 adain_resblock1(G + "resblocks." + std::to_string(st * 3 + j), ks[j], xu, xj, t1, xs, j > 0 ? 1 : 0,
-                                j == 2 ? 3.0f : 1.0f);
+                                j == 2 ? 3.0f : 1.0f, part_t1, part_xj);
             tap(("gen.stage." + std::to_string(st)).c_str(), xs);
             x = xs;
         }
