@@ -157,10 +157,19 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; KX_DIST_BACKEND=gloo + KX_SHARE_GPU=1 rehearse the N>1 path on a 1-GPU box
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % n_dev if os.environ.get("KX_SHARE_GPU") == "1" else local_rank
+    if dev_index >= n_dev:
+        raise SystemExit(f"LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = os.environ.get("KX_DIST_BACKEND", "nccl")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # ---- weights: rank 0 owns the file, everyone else gets it over RCCL/xGMI once ----------
     progress("preparing synthetic weight blob")
@@ -170,7 +179,7 @@ def main():
     torch.cuda.synchronize()
     t_bcast = time.perf_counter() - t0
     progress(f"blob on device ({t_bcast:.2f} s); building model")
-    model = hk.HipKoko.from_device_blob(blob.data_ptr(), blob.numel(), device=local_rank)
+    model = hk.HipKoko.from_device_blob(blob.data_ptr(), blob.numel(), device=dev_index)
     del blob
     progress("model ready")
 
@@ -229,7 +238,7 @@ def main():
             for key, (n, fl, ms) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
                 f.write(" ".join(f"{v:5d}" for v in key) + f" {n:4d} {fl / 1e9:10.1f} {ms:9.3f} {fl / ms / 1e9:8.1f}\n")
     model.profile_enable(False)
-    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall = float(wall_t.item())

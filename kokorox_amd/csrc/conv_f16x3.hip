@@ -71,10 +71,12 @@ __device__ __forceinline__ void glds16(const uint4* gsrc_lane, uint4* lds_wave_b
 }
 
 template <int BM, int BN, int WM, int WN, int ACT, int TK, bool PF>
-__global__ __launch_bounds__(256, (BM / WM / 32) * (BN / WN / 32) > 4 ? 2 : 3) void conv1d_f16x3_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((BM / WM / 32) * (BN / WN / 32) > 4 ? 2 : 3))
+void conv1d_f16x3_kernel(const ConvArgs a) {
     constexpr int MT = BM / WM / 32;
     constexpr int NT = BN / WN / 32;
-    static_assert(WM * WN == 4 && MT >= 1 && NT >= 1, "4 waves per workgroup");
+    constexpr int NWV = WM * WN;  // waves per workgroup: 4, or 8 (same tile, half the registers per wave)
+    static_assert((NWV == 4 || NWV == 8) && MT >= 1 && NT >= 1, "4 or 8 waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
 
     const int tid = threadIdx.x;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256, (BM / WM / 32) * (BN / WN / 32) > 4 ? 2 : 3) v
         uint4* dst = Wbuf + buf * piece_units;
         const int nseg = taps * tap_units / 64;
         if (a.dbg & 2) return;
-        for (int sgm = wave; sgm < nseg; sgm += 4) glds16(src + sgm * 64 + lane, dst + sgm * 64);
+        for (int sgm = wave; sgm < nseg; sgm += NWV) glds16(src + sgm * 64 + lane, dst + sgm * 64);
     };
 
     // ---- input chunk staging.  Wave w takes channel pairs w and w+4 of the chunk's 8 pairs; per-channel
@@ -135,9 +137,10 @@ __global__ __launch_bounds__(256, (BM / WM / 32) * (BN / WN / 32) > 4 ? 2 : 3) v
     // chunk are loaded into registers before the MFMA loop of the current one (their latency hides behind
     // the matrix work) and are transformed + written after it.
     constexpr int NI = 5;  // PF needs XW <= 64 * NI (the launcher checks)
-    float raw[2][NI][2];
+    constexpr int NH = 8 / NWV;  // channel pairs staged per wave
+    float raw[NH][NI][2];
     // per-lane element offsets of this lane's NI window columns (they do not depend on the chunk)
-    long xoff[NI];
+    int xoff[NI];
     unsigned okmask = 0;
     if (PF) {
 #pragma unroll
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256, (BM / WM / 32) * (BN / WN / 32) > 4 ? 2 : 3) v
                 const int bb = pc / a.merge_T, tt = pc - bb * a.merge_T;
                 const bool ok = p < Lin && tt < a.in_len.lens[bb];
                 okmask |= ok ? (1u << it) : 0u;
-                xoff[it] = (long)bb * a.x_bs + tt;
+                xoff[it] = (int)((long)bb * a.x_bs + tt);
             } else {
                 okmask |= (p >= 0 && p < Lin) ? (1u << it) : 0u;
                 int pi = up2 ? (p >> 1) : p;
@@ -160,8 +163,8 @@ __global__ __launch_bounds__(256, (BM / WM / 32) * (BN / WN / 32) > 4 ? 2 : 3) v
     const float* xbase = merged ? a.x : xb;
     auto load_raw = [&](int ch) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int cA = ch * CK16 + 2 * (wave + 4 * half), cB = cA + 1;
+        for (int half = 0; half < NH; ++half) {
+            const int cA = ch * CK16 + 2 * (wave + NWV * half), cB = cA + 1;
             const float* rowA = xbase + (long)(cA < a.Cin ? cA : 0) * a.x_ld;
             const float* rowB = xbase + (long)(cB < a.Cin ? cB : 0) * a.x_ld;
 #pragma unroll
@@ -173,8 +176,8 @@ __global__ __launch_bounds__(256, (BM / WM / 32) * (BN / WN / 32) > 4 ? 2 : 3) v
     };
     auto stage_chunk = [&](int ch, bool from_raw) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int pr = wave + 4 * half;  // pair index 0..7 inside the 16-channel chunk
+        for (int half = 0; half < NH; ++half) {
+            const int pr = wave + NWV * half;  // pair index 0..7 inside the 16-channel chunk
             const int cA = ch * CK16 + 2 * pr, cB = cA + 1;
             const bool okA = cA < a.Cin, okB = cB < a.Cin;
             const int cAc = okA ? cA : 0, cBc = okB ? cB : 0;  // clamped: loads stay in bounds, result masked
@@ -340,7 +343,7 @@ static void launch_inst16_pf(const ConvArgs& a, int B, int max_cols, hipStream_t
     KX_REQUIRE(a.merge_T == 0 || (PF && a.K == 1 && a.stride == 1 && a.pad == 0 && !a.in_up2 && !a.nmean &&
                                   a.store != ST_UPSCATTER && !a.stat_part),
                "conv1d f16x3: merged columns need a plain k=1 GEMM");
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, a);
     KX_HIP(hipGetLastError());
 }
 
@@ -386,6 +389,7 @@ void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStre
     KX_REQUIRE(a.n_chunks16 == (a.Cin + CK16 - 1) / CK16 && a.w16 != nullptr, "conv1d f16x3: weights not packed");
     if (max_cols <= 0) return;
     if (BM == 128) {
+        // (an 8-wave x 128-register form of the 128x256 tile was tried: it spills and is 6 % slower)
         if (conv16_pick_bn(BM, max_cols) == 128)
             launch_inst16<128, 128, 2, 2>(a, B, max_cols, s);
         else

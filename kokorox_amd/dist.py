@@ -43,8 +43,18 @@ def broadcast_blob(path_on_rank0: str, device, rank: int, world: int):
     else:
         host = None
         n = torch.zeros(1, dtype=torch.int64, device=device)
+    gloo = world > 1 and dist.get_backend() == "gloo"
     if world > 1:
-        dist.broadcast(n, src=0)
+        if gloo:  # CPU rehearsal backend: collectives on host tensors
+            n_h = n.cpu()
+            dist.broadcast(n_h, src=0)
+            n = n_h
+        else:
+            dist.broadcast(n, src=0)
+    if gloo:
+        buf_h = host if rank == 0 else torch.empty(int(n.item()), dtype=torch.uint8)
+        dist.broadcast(buf_h, src=0)
+        return buf_h.to(device)
     buf = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
     if rank == 0:
         buf.copy_(host)

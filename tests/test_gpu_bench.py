@@ -1,0 +1,44 @@
+"""GPU: bench.py's contract — one JSON line with the required fields — at N=1 and, as a rehearsal of the
+multi-rank path on a 1-GPU box, at N=2 over gloo with both ranks sharing the card (the real runs use
+one GPU per rank over RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _last_json(out: str):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line():
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--batch", "4", "--cpu-utts", "1",
+                        "--free-run", "0"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert REQUIRED <= set(d)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["higher_is_better"] and d["vs_baseline"] is None
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_bench_two_ranks_rehearsal():
+    env = dict(os.environ, KX_DIST_BACKEND="gloo", KX_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "1",
+                        "--warmup", "1", "--batch", "4", "--cpu-utts", "0", "--free-run", "0"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert abs(d["audio_s_per_step"] - 2 * 4 * 10.55) < 1e-6
