@@ -31,7 +31,8 @@ __device__ __forceinline__ float half_wave_sum(float x) {
 }
 
 // acc scale: the f16x3 path carries the 2^ws weight pre-scale in its accumulators
-template <int MT, int NT>
+// EB = rows per load batch of the read-modify-write path (8 or 16)
+template <int MT, int NT, int EB = 8>
 __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)[MT][NT], float acc_scale, int b,
                                                 int row0, int col0, int r, int h, int ncols, int Lout, int stat_slot) {
     if (a.store == ST_NORMAL || a.store == ST_TMAJOR) {
@@ -61,13 +62,13 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-            for (int eg = 0; eg < 2; ++eg) {
-                float rv[8][NT], yv[8][NT], bv[8];
-                long yo[8];
-                bool rok[8];
+            for (int eg = 0; eg < 16 / EB; ++eg) {
+                float rv[EB][NT], yv[EB][NT], bv[EB];
+                long yo[EB];
+                bool rok[EB];
 #pragma unroll
-                for (int e8 = 0; e8 < 8; ++e8) {
-                    const int e = eg * 8 + e8;
+                for (int e8 = 0; e8 < EB; ++e8) {
+                    const int e = eg * EB + e8;
                     const int row = row0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     rok[e8] = row < a.Cout;
                     const int rowc = row < rmax ? row : rmax;
@@ -80,14 +81,14 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)
                         yv[e8][nt] = accum ? a.y[yo[e8] + ycol[nt]] : 0.f;
                     }
                 }
-                float rs[8], rq[8];
+                float rs[EB], rq[EB];
 #pragma unroll
-                for (int e8 = 0; e8 < 8; ++e8) {
+                for (int e8 = 0; e8 < EB; ++e8) {
                     rs[e8] = 0.f;
                     rq[e8] = 0.f;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        float v = acc[mt][nt][eg * 8 + e8] * acc_scale + bv[e8];
+                        float v = acc[mt][nt][eg * EB + e8] * acc_scale + bv[e8];
                         if (has_res) v += rv[e8][nt];
                         if (accum) v += yv[e8][nt];
                         v *= a.out_mul;
@@ -103,10 +104,10 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)
                     // fused InstanceNorm statistics of what was just stored: reduce each row's partial over the
                     // 32 lanes of this half-wave (lanes = columns), one (sum, sumsq) per row and column slot
 #pragma unroll
-                    for (int e8 = 0; e8 < 8; ++e8) {
+                    for (int e8 = 0; e8 < EB; ++e8) {
                         const float sv = half_wave_sum(rs[e8]), qv = half_wave_sum(rq[e8]);
                         if (r == 0 && rok[e8]) {
-                            const int e = eg * 8 + e8;
+                            const int e = eg * EB + e8;
                             const int row = row0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                             a.stat_part[((long)b * a.Cout + row) * a.stat_tiles + stat_slot] = make_float2(sv, qv);
                         }

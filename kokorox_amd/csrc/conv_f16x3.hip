@@ -24,6 +24,10 @@ namespace kx {
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using half2v = __attribute__((ext_vector_type(2))) _Float16;
 
+#ifndef KX_EPI_ROWS
+#define KX_EPI_ROWS 8
+#endif
+constexpr int EPI_ROWS = KX_EPI_ROWS;  // rows per epilogue load batch
 constexpr int CK16 = 16;  // input channels per K-chunk
 constexpr int TK_MAX = 3;  // taps per weight piece in LDS (template parameter TK <= this)
 
@@ -71,7 +75,7 @@ __device__ __forceinline__ void glds16(const uint4* gsrc_lane, uint4* lds_wave_b
 }
 
 template <int BM, int BN, int WM, int WN, int ACT, int TK, bool PF>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((BM / WM / 32) * (BN / WN / 32) > 4 ? 2 : 3))
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((BM / WM / 32) * (BN / WN / 32) > 6 ? 2 : 3))
 void conv1d_f16x3_kernel(const ConvArgs a) {
     constexpr int MT = BM / WM / 32;
     constexpr int NT = BN / WN / 32;
@@ -306,7 +310,7 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
     if (a.stamps) st2 = __builtin_amdgcn_s_memrealtime();
     // ---- epilogue (conv_epilogue.h); accumulators carry the 2^ws weight scale -----------------------
     if (a.dbg & 8) return;
-    conv_store_tile<MT, NT>(a, acc, a.w_unscale, b, ct * BM + wm * (MT * 32), t0 + wn * (NT * 32), r, h, ncols, Lout,
+    conv_store_tile<MT, NT, EPI_ROWS>(a, acc, a.w_unscale, b, ct * BM + wm * (MT * 32), t0 + wn * (NT * 32), r, h, ncols, Lout,
                             blockIdx.x * WN + wn);
     if (a.stamps && tid == 0) {  // stamps leave through a buffer of their own that nothing else reads
         const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -390,6 +394,7 @@ void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStre
     if (max_cols <= 0) return;
     if (BM == 128) {
         // (an 8-wave x 128-register form of the 128x256 tile was tried: it spills and is 6 % slower)
+        // (also tried: a 128x192 tile for 3 workgroups per CU: the 168-register cap spills in the main loop, 1.7x slower)
         if (conv16_pick_bn(BM, max_cols) == 128)
             launch_inst16<128, 128, 2, 2>(a, B, max_cols, s);
         else
