@@ -65,37 +65,54 @@ void launch_embed(const int64_t* ids, long ids_stride, const float* table, int C
 }
 
 // ---- channel layer-norm -------------------------------------------------------------------
-// 64 time columns x 4 channel groups per workgroup; reads are coalesced along time.
-__global__ __launch_bounds__(256) void layernorm_ch_kernel(const float* x, float* y, long bs, int ld, int C,
-                                                           LenMap len, float eps, int mode, const float* g,
-                                                           const float* be, int g_bs, float leaky) {
-    __shared__ float red[4][64];
+// 64 time columns x 16 channel groups per workgroup (1024 threads); reads are coalesced along time.
+// Each thread keeps its CPT = C/16 channel values in registers, so the tensor is read once:
+// mean (LDS reduce over the 16 groups) -> centred sum of squares (reduce) -> normalise + write.
+template <int CPT>
+__global__ __launch_bounds__(1024) void layernorm_ch_kernel(const float* x, float* y, long bs, int ld, int C,
+                                                            LenMap len, float eps, int mode, const float* g,
+                                                            const float* be, int g_bs, float leaky) {
+    __shared__ float red[16][64];
     const int tx = threadIdx.x & 63, cg = threadIdx.x >> 6;
     const int b = blockIdx.y, t = blockIdx.x * 64 + tx;
     const int L = len_of(len, b);
     const bool ok = t < L;
-    const float* xb = x + b * bs + t;
+    const float* xb = x + b * bs + (ok ? t : 0);
+    float v[CPT];
     float s = 0.f;
-    if (ok)
-        for (int c = cg; c < C; c += 4) s += xb[(long)c * ld];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = cg + 16 * i;
+        v[i] = (ok && c < C) ? xb[(long)c * ld] : 0.f;
+        s += v[i];
+    }
     red[cg][tx] = s;
     __syncthreads();
-    const float mean = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) / (float)C;
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += red[k][tx];
+    const float mean = tot / (float)C;
     __syncthreads();
-    float v = 0.f;
-    if (ok)
-        for (int c = cg; c < C; c += 4) {
-            float d = xb[(long)c * ld] - mean;
-            v += d * d;
-        }
-    red[cg][tx] = v;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = cg + 16 * i;
+        const float d = (c < C) ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    red[cg][tx] = q;
     __syncthreads();
-    const float var = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) / (float)C;
-    const float rstd = 1.0f / sqrtf(var + eps);
+    float qt = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) qt += red[k][tx];
+    const float rstd = 1.0f / sqrtf(qt / (float)C + eps);
     if (!ok) return;
     float* yb = y + b * bs + t;
-    for (int c = cg; c < C; c += 4) {
-        float o = (xb[(long)c * ld] - mean) * rstd;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = cg + 16 * i;
+        if (c >= C) continue;
+        float o = (v[i] - mean) * rstd;
         if (mode == LN_AFFINE)
             o = o * g[c] + be[c];
         else if (mode == LN_ADA)
@@ -107,8 +124,14 @@ __global__ __launch_bounds__(256) void layernorm_ch_kernel(const float* x, float
 void launch_layernorm_ch(const float* x, float* y, long bs, int ld, int C, LenMap len, int B, int Lmax, float eps,
                          int mode, const float* g, const float* be, int g_bs, float leaky, hipStream_t s) {
     if (Lmax <= 0) return;
-    hipLaunchKernelGGL(layernorm_ch_kernel, dim3((Lmax + 63) / 64, B), dim3(256), 0, s, x, y, bs, ld, C, len, eps,
-                       mode, g, be, g_bs, leaky);
+    KX_REQUIRE(C <= 768, "layernorm: at most 768 channels");
+    const dim3 grid((Lmax + 63) / 64, B), block(1024);
+    if (C <= 128)
+        hipLaunchKernelGGL(layernorm_ch_kernel<8>, grid, block, 0, s, x, y, bs, ld, C, len, eps, mode, g, be, g_bs, leaky);
+    else if (C <= 512)
+        hipLaunchKernelGGL(layernorm_ch_kernel<32>, grid, block, 0, s, x, y, bs, ld, C, len, eps, mode, g, be, g_bs, leaky);
+    else
+        hipLaunchKernelGGL(layernorm_ch_kernel<48>, grid, block, 0, s, x, y, bs, ld, C, len, eps, mode, g, be, g_bs, leaky);
     KX_HIP(hipGetLastError());
 }
 
@@ -174,19 +197,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* qkv, long b
     }
 }
 // LDS form for T <= 256: K [64][Tp] and V^T [T][65] of the head are staged once per workgroup, so the
-// score and P.V loops read only LDS (lane-contiguous, conflict-free) instead of re-streaming K/V from L2
-// for every query row.
+// score and P.V loops read only LDS (lane-contiguous, conflict-free).  Each wave works on TWO query rows at
+// a time (every K / V value read from LDS serves both), and the query rows of one (utterance, head) are
+// split over `qsplit` workgroups so that small batches still fill the chip.
 __global__ __launch_bounds__(256) void attention_lds_kernel(const float* qkv, long bs, int ld, float* ctx, long cbs,
-                                                            int cld, const int* lens) {
+                                                            int cld, const int* lens, int qsplit) {
     extern __shared__ __attribute__((aligned(16))) float att_smem[];
-    const int b = blockIdx.x, hd = blockIdx.y;
+    const int b = blockIdx.x / qsplit, qs_id = blockIdx.x - b * qsplit, hd = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int T = lens[b];
     const int Tp = (T + 3) & ~3;
     float* Ks = att_smem;               // [64][Tp]
     float* Vt = Ks + 64 * Tp;           // [T][65]
-    float* ps = Vt + T * 65;            // [4][Tp]
-    float* qs = ps + 4 * Tp;            // [4][64]
+    float* ps = Vt + T * 65;            // [4 waves][2][Tp]
+    float* qs = ps + 8 * Tp;            // [4 waves][2][64]
     const float* Q = qkv + b * bs + (long)(hd * 64) * ld;
     const float* Kp = Q + (long)768 * ld;
     const float* V = Q + (long)1536 * ld;
@@ -197,48 +221,77 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(const float* qkv, lo
     }
     __syncthreads();
     const int nslot = (T + 63) >> 6;  // <= 4
-    float* pw = ps + wave * Tp;
-    float* qw = qs + wave * 64;
-    for (int i = wave; i < T; i += 4) {
-        qw[lane] = Q[(long)lane * ld + i];
+    float* pw0 = ps + (wave * 2) * Tp;
+    float* pw1 = pw0 + Tp;
+    float* qw0 = qs + (wave * 2) * 64;
+    float* qw1 = qw0 + 64;
+    const int npair = (T + 1) >> 1;
+    for (int pq = qs_id * 4 + wave; pq < npair; pq += 4 * qsplit) {
+        const int i0 = 2 * pq, i1 = (2 * pq + 1 < T) ? 2 * pq + 1 : i0;
+        qw0[lane] = Q[(long)lane * ld + i0];
+        qw1[lane] = Q[(long)lane * ld + i1];
         __builtin_amdgcn_wave_barrier();
-        float sc[4] = {0.f, 0.f, 0.f, 0.f};
+        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
         for (int d = 0; d < 64; ++d) {
-            const float qd = qw[d];
+            const float q0 = qw0[d], q1 = qw1[d];
             const float* kr = Ks + d * Tp;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int j = lane + 64 * m;
-                if (m < nslot && j < T) sc[m] += qd * kr[j];
+                if (m < nslot && j < T) {
+                    const float kv = kr[j];
+                    s0[m] += q0 * kv;
+                    s1[m] += q1 * kv;
+                }
             }
         }
-        float mx = -INFINITY;
+        float mx0 = -INFINITY, mx1 = -INFINITY;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int j = lane + 64 * m;
-            sc[m] = (m < nslot && j < T) ? sc[m] * 0.125f : -INFINITY;
-            mx = fmaxf(mx, sc[m]);
+            const bool okj = m < nslot && j < T;
+            s0[m] = okj ? s0[m] * 0.125f : -INFINITY;
+            s1[m] = okj ? s1[m] * 0.125f : -INFINITY;
+            mx0 = fmaxf(mx0, s0[m]);
+            mx1 = fmaxf(mx1, s1[m]);
         }
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        float sum = 0.f;
+        for (int o = 32; o > 0; o >>= 1) {
+            mx0 = fmaxf(mx0, __shfl_xor(mx0, o));
+            mx1 = fmaxf(mx1, __shfl_xor(mx1, o));
+        }
+        float sum0 = 0.f, sum1 = 0.f;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int j = lane + 64 * m;
             if (m < nslot && j < T) {
-                sc[m] = expf(sc[m] - mx);
-                sum += sc[m];
+                s0[m] = expf(s0[m] - mx0);
+                s1[m] = expf(s1[m] - mx1);
+                sum0 += s0[m];
+                sum1 += s1[m];
             }
         }
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        for (int o = 32; o > 0; o >>= 1) {
+            sum0 += __shfl_xor(sum0, o);
+            sum1 += __shfl_xor(sum1, o);
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int j = lane + 64 * m;
-            if (m < nslot && j < T) pw[j] = sc[m] / sum;
+            if (m < nslot && j < T) {
+                pw0[j] = s0[m] / sum0;
+                pw1[j] = s1[m] / sum1;
+            }
         }
         __builtin_amdgcn_wave_barrier();
-        float o = 0.f;
-        for (int j = 0; j < T; ++j) o += pw[j] * Vt[j * 65 + lane];
-        ctx[b * cbs + (long)(hd * 64 + lane) * cld + i] = o;
+        float o0 = 0.f, o1 = 0.f;
+        for (int j = 0; j < T; ++j) {
+            const float vv = Vt[j * 65 + lane];
+            o0 += pw0[j] * vv;
+            o1 += pw1[j] * vv;
+        }
+        float* crow = ctx + b * cbs + (long)(hd * 64 + lane) * cld;
+        crow[i0] = o0;
+        if (i1 != i0) crow[i1] = o1;
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -248,14 +301,17 @@ void launch_attention(const float* qkv, long bs, int ld, float* ctx, long cbs, i
     KX_REQUIRE(Tmax <= 512, "attention: T > 512");
     if (Tmax <= 256) {
         const int Tp = (Tmax + 3) & ~3;
-        const size_t lds = sizeof(float) * ((size_t)64 * Tp + (size_t)Tmax * 65 + 4 * Tp + 4 * 64);
+        const size_t lds = sizeof(float) * ((size_t)64 * Tp + (size_t)Tmax * 65 + 8 * Tp + 8 * 64);
         static size_t lds_limit = 64 * 1024;
         if (lds > lds_limit) {
             KX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_lds_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             lds_limit = lds;
         }
-        hipLaunchKernelGGL(attention_lds_kernel, dim3(B, 12), dim3(256), lds, s, qkv, bs, ld, ctx, cbs, cld, lens);
+        int qsplit = 512 / (B * 12);  // aim at >= 2 workgroups per CU
+        qsplit = qsplit < 1 ? 1 : (qsplit > 8 ? 8 : qsplit);
+        hipLaunchKernelGGL(attention_lds_kernel, dim3(B * qsplit, 12), dim3(256), lds, s, qkv, bs, ld, ctx, cbs, cld,
+                           lens, qsplit);
     } else {
         hipLaunchKernelGGL(attention_kernel, dim3(B, 12), dim3(256), 0, s, qkv, bs, ld, ctx, cbs, cld, lens);
     }
