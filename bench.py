@@ -66,19 +66,19 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def pmc_traffic(B, T, F):
+def pmc_traffic(B, T, F, mode):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/*pmc_conv_traffic.json, written by tools/summarize_pmc.py for this same workload);
     None when no pass matches.  PMC passes cannot run inside this process."""
     import glob
     best = None
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_conv_traffic.json"))):
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_conv_traffic*.json"))):
         try:
             d = json.load(open(p))
         except Exception:
             continue
         w = d.get("workload", {})
-        if (w.get("batch"), w.get("tokens"), w.get("frames")) == (B, T, F):
+        if (w.get("batch"), w.get("tokens"), w.get("frames"), w.get("conv_mode", "f32")) == (B, T, F, mode):
             best = d
     return None if best is None else best["traffic_bytes_per_launch"]
 
@@ -96,7 +96,7 @@ def roofline(f16x3, conv_flops, conv_ms, n_launch, steps, wall, B, T, F):
     kern = ("kx::conv1d_f16x3_kernel<128,{256|128},2,2,ACT> (f16 32x32x16 MFMA x3, implicit GEMM)" if f16x3
             else "kx::conv1d_mfma_kernel<128,128,2,2> (f32 32x32x2 MFMA implicit GEMM)")
     out = {"bound": "mfma", "kernel": kern, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-           "traffic": pmc_traffic(B, T, F) if not f16x3 else None,
+           "traffic": pmc_traffic(B, T, F, "f16x3" if f16x3 else "f32"),
            "launches_per_step": n_launch / max(steps, 1), "avg_launch_ms": conv_ms / max(n_launch, 1),
            "gflop_per_launch": conv_flops / max(n_launch, 1) / 1e9, "kernel_share_of_wall": conv_ms * 1e-3 / wall}
     if f16x3:

@@ -31,16 +31,17 @@ __device__ __forceinline__ float half_wave_sum(float x) {
 }
 
 // acc scale: the f16x3 path carries the 2^ws weight pre-scale in its accumulators
-// EB = rows per load batch of the read-modify-write path (8 or 16)
-template <int MT, int NT, int EB = 8>
-__device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)[MT][NT], float acc_scale, int b,
-                                                int row0, int col0, int r, int h, int ncols, int Lout, int stat_slot) {
-    if (a.store == ST_NORMAL || a.store == ST_TMAJOR) {
+// read-modify-write store of one wave's tile (channel-major or time-major), EB rows per load batch
+template <int MT, int NT, int EB, bool ACCUM>
+__device__ __forceinline__ void conv_store_rmw(const ConvArgs& a, f32x16 (&acc)[MT][NT], float acc_scale, int b,
+                                               int row0, int col0, int r, int h, int ncols, int stat_slot) {
+    {
         // Latency-bound read-modify-write of the tile: issue the residual / accumulate loads of 8 rows x NT
         // columns back to back (addresses clamped so the loads need no branches), then combine and store.
         const bool tmaj = a.store == ST_TMAJOR;
         const bool has_res = a.resid != nullptr && !tmaj, has_bias = a.bias != nullptr;
-        const bool accum = a.accum != 0 && !tmaj, gelu = a.epi == EPI_GELU_NEW, do_div = a.out_div != 1.0f;
+        constexpr bool accum = ACCUM;
+        const bool gelu = a.epi == EPI_GELU_NEW, do_div = a.out_div != 1.0f;
         const int cmax = ncols - 1, rmax = a.Cout - 1;
         // per-column element offsets (without the row term); merged mode maps column -> (utterance, t)
         long ycol[NT], rcol[NT];
@@ -63,7 +64,7 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int eg = 0; eg < 16 / EB; ++eg) {
-                float rv[EB][NT], yv[EB][NT], bv[EB];
+                float rv[EB][NT], yv[ACCUM ? EB : 1][NT], bv[EB];
                 long yo[EB];
                 bool rok[EB];
 #pragma unroll
@@ -78,7 +79,7 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         rv[e8][nt] = has_res ? a.resid[ro + rcol[nt]] : 0.f;
-                        yv[e8][nt] = accum ? a.y[yo[e8] + ycol[nt]] : 0.f;
+                        if (ACCUM) yv[e8][nt] = a.y[yo[e8] + ycol[nt]];
                     }
                 }
                 float rs[EB], rq[EB];
@@ -90,7 +91,7 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)
                     for (int nt = 0; nt < NT; ++nt) {
                         float v = acc[mt][nt][eg * EB + e8] * acc_scale + bv[e8];
                         if (has_res) v += rv[e8][nt];
-                        if (accum) v += yv[e8][nt];
+                        if (ACCUM) v += yv[e8][nt];
                         v *= a.out_mul;
                         if (do_div) v = v / a.out_div;
                         if (gelu) v = gelu_new_f(v);
@@ -115,6 +116,18 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)
                 }
             }
         }
+    }
+}
+
+// EB = rows per load batch of the read-modify-write path (8 or 16)
+template <int MT, int NT, int EB = 8>
+__device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)[MT][NT], float acc_scale, int b,
+                                                int row0, int col0, int r, int h, int ncols, int Lout, int stat_slot) {
+    if (a.store == ST_NORMAL || a.store == ST_TMAJOR) {
+        if (a.accum != 0 && a.store == ST_NORMAL)
+            conv_store_rmw<MT, NT, EB, true>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot);
+        else
+            conv_store_rmw<MT, NT, EB, false>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot);
         return;
     }
     // ST_UPSCATTER: polyphase transposed conv, GEMM row (p, co), column q -> out[co][s*q + p - pad]

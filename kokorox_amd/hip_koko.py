@@ -39,7 +39,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("KX_LIB") or LIB_PATH
     if not os.path.exists(p):
         raise FileNotFoundError(
             f"{p} is missing: build it with `python -m kokorox_amd.build` (hipcc, gfx950). "
