@@ -124,6 +124,22 @@ int kx_profile_read(kx_model* m, int64_t* launches, double* total_ms, double* to
  * stride, store form, summed columns, FLOPs, milliseconds.  out = NULL returns the count only. */
 int kx_profile_detail(kx_model* m, double* out, int64_t cap_rows, int64_t* n_rows);
 
+/* ---- request dispatcher ----------------------------------------------------
+ * Replaces the reference's one-request-at-a-time `Mutex<Session>` (kokorox/src/onn/ort_koko.rs:78; callers
+ * kokorox-openai/src/lib.rs:370-439, kokorox-websocket/src/lib.rs:657-668).  Any number of threads submit
+ * single utterances; one worker per model (= per GPU) coalesces whatever is queued — up to max_batch, waiting
+ * at most max_wait_us after the first arrival — into one batched forward.  A request's waveform depends only
+ * on (ids, style, speed, seed), not on what it was batched with. */
+typedef struct kx_dispatcher kx_dispatcher;
+kx_dispatcher* kx_dispatcher_create(kx_model** models, int n_models, int max_batch, int max_wait_us, char* err,
+                                    size_t err_len);
+/* Blocking; thread-safe.  ids = n_tokens ids incl. the two 0 pads; style = 256 floats.  *out is malloc'd
+ * (free with kx_free_audio).  Equals kx_infer(B = 1, same seed, utterance base 0) bit for bit. */
+int kx_dispatcher_submit(kx_dispatcher* d, const int64_t* ids, int n_tokens, const float* style, float speed,
+                         uint64_t seed, float** out, int64_t* out_len, char* err, size_t err_len);
+int kx_dispatcher_stats(kx_dispatcher* d, int64_t* n_requests, int64_t* n_batches, int64_t* max_batch_seen);
+void kx_dispatcher_destroy(kx_dispatcher* d);  /* waits for queued requests; models stay alive */
+
 /* ---- test hooks (used by tests/ only) --------------------------------------------- */
 
 /* Named intermediate of the last kx_infer*(…, KX_FLAG_TAPS): utterance b's [C, L] slab

@@ -9,8 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libkokorox_hip.so")
-SOURCES = ["conv_mfma.hip", "conv_f16x3.hip", "kernels_misc.hip", "model.hip", "api.hip"]
-HEADERS = ["kx_common.h", "model.h", os.path.join("..", "..", "include", "kokorox_hip.h")]
+SOURCES = ["conv_mfma.hip", "conv_f16x3.hip", "kernels_misc.hip", "model.hip", "api.hip", "dispatcher.hip"]
+HEADERS = ["kx_common.h", "model.h", "kx_handle.h", "conv_epilogue.h", os.path.join("..", "..", "include", "kokorox_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-result"]
 
 
@@ -43,7 +43,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)
     if force or not _newer(LIB_PATH, objs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lpthread", "-o", LIB_PATH]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)

@@ -8,9 +8,7 @@
 using kx::Error;
 using kx::Model;
 
-struct kx_model {
-    std::unique_ptr<Model> m;
-};
+#include "kx_handle.h"
 
 static void set_err(char* err, size_t n, const std::string& msg) {
     if (err && n) {
@@ -372,7 +370,7 @@ int kx_test_source(int device_id, const float* f0, int B, int F2, const float* l
         const float* d_b = dm.up(&lin_b, 1);
         float* phase = dm.get<float>((size_t)B * 9 * F2);
         float* har = dm.get<float>((size_t)B * 600 * F);
-        kx::launch_source(d_f0, F2, d_fr, B, F, d_w, d_b, seed, utt_base, noise_off, phase, har, (long)600 * F, nullptr);
+        kx::launch_source(d_f0, F2, d_fr, B, F, d_w, d_b, seed, utt_base, nullptr, noise_off, phase, har, (long)600 * F, nullptr);
         KX_HIP(hipDeviceSynchronize());
         KX_HIP(hipMemcpy(out, har, (size_t)B * 600 * F * 4, hipMemcpyDeviceToHost));
     });

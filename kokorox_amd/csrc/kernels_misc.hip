@@ -631,7 +631,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 __global__ void source_sample_kernel(const float* f0, long f0_bs, const int* frames, const float* phase, int L2max,
                                      const float* lin_w, const float* lin_b, uint32_t k0, uint32_t k1,
-                                     uint64_t utt_base, int noise_off, float* har, long har_bs) {
+                                     uint64_t utt_base, const uint64_t* utt_seeds, int noise_off, float* har,
+                                     long har_bs) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     const int n2 = 2 * frames[b];
     if (j >= 300 * n2) return;
@@ -644,7 +645,13 @@ __global__ void source_sample_kernel(const float* f0, long f0_bs, const int* fra
     const float l1 = __fsub_rn(src, (float)i0), l0 = __fsub_rn(1.0f, l1);
     const int i1 = i0 + (i0 < n2 - 1 ? 1 : 0);
     const float amp = uv ? 0.003f : (0.1f / 3.0f);
-    const uint32_t utt = (uint32_t)(utt_base + (uint64_t)b);
+    // per-utterance keys (dispatcher): stream (seed_b, utterance 0); otherwise (seed, utt_base + b)
+    uint32_t utt = (uint32_t)(utt_base + (uint64_t)b);
+    if (utt_seeds) {
+        k0 = (uint32_t)(utt_seeds[b] & 0xFFFFFFFFu);
+        k1 = (uint32_t)(utt_seeds[b] >> 32);
+        utt = 0u;
+    }
     float acc = 0.f;
 #pragma unroll
     for (int h = 0; h < 9; ++h) {
@@ -667,14 +674,14 @@ __global__ void source_sample_kernel(const float* f0, long f0_bs, const int* fra
 }
 
 void launch_source(const float* f0, long f0_bs, const int* frames, int B, int Fmax, const float* lin_w,
-                   const float* lin_b, uint64_t seed, uint64_t utt_base, int noise_off, float* phase_ws, float* har,
-                   long har_bs, hipStream_t s) {
+                   const float* lin_b, uint64_t seed, uint64_t utt_base, const uint64_t* utt_seeds, int noise_off,
+                   float* phase_ws, float* har, long har_bs, hipStream_t s) {
     const int L2max = 2 * Fmax;
     hipLaunchKernelGGL(source_phase_kernel, dim3(B), dim3(64), 0, s, f0, f0_bs, frames, phase_ws, L2max);
     KX_HIP(hipGetLastError());
     hipLaunchKernelGGL(source_sample_kernel, dim3((600 * Fmax + 255) / 256, B), dim3(256), 0, s, f0, f0_bs, frames,
                        phase_ws, L2max, lin_w, lin_b, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32),
-                       utt_base, noise_off, har, har_bs);
+                       utt_base, utt_seeds, noise_off, har, har_bs);
     KX_HIP(hipGetLastError());
 }
 

@@ -177,7 +177,8 @@ void launch_pool_up2(const float* x, long xbs, int xld, int C, const float* mean
                      long ybs, int yld, LenMap in_len, int B, int Lmax_in, hipStream_t s);
 
 void launch_source(const float* f0, long f0_bs, const int* frames, int B, int Fmax, const float* lin_w,
-                   const float* lin_b, uint64_t seed, uint64_t utt_base, int noise_off, float* phase_ws,
+                   const float* lin_b, uint64_t seed, uint64_t utt_base, const uint64_t* utt_seeds, int noise_off,
+                   float* phase_ws,
                    float* har, long har_bs, hipStream_t s);
 void launch_stft(const float* har_src, long hs_bs, float* har, long bs, int ld, const int* frames, int B,
                  int Fmax, hipStream_t s);

@@ -98,7 +98,7 @@ class Model {
                       float* d_audio, int64_t audio_ld, int32_t* d_frames, int64_t* need_ld);
     void infer_host(const int64_t* ids, int64_t t_stride, const int32_t* lens, int B, const float* styles,
                     const float* speeds, int n_speed, uint64_t seed, uint32_t flags, float** out,
-                    int64_t* out_lens);
+                    int64_t* out_lens, const uint64_t* utt_seeds = nullptr);
     void sync();
     void set_pinned(const int32_t* pattern, int n);
     void profile_enable(bool on);
@@ -150,6 +150,7 @@ class Model {
     long gb_total_ = 0;
 
     Arena arenaT_, arenaF_, arenaIO_;
+    const uint64_t* d_utt_seeds_ = nullptr;  // per-utterance noise keys of the running call (dispatcher)
     int* d_pinned_ = nullptr;
     int n_pinned_ = 0;
 

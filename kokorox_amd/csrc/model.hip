@@ -884,7 +884,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
         float* phase = A.f((size_t)B * 9 * 2 * Fmax);
         if (!dry_)
             launch_source(curves.p, curves.bs, dF_, B, Fmax, wt(G + "m_source.l_linear.weight"),
-                          wt(G + "m_source.l_linear.bias"), seed, utt_base, noise_off, phase, har_src, hs_ld, stream_);
+                          wt(G + "m_source.l_linear.bias"), seed, utt_base, d_utt_seeds_, noise_off, phase, har_src, hs_ld, stream_);
         if (taps_on_ && !dry_) {
             T hs;
             hs.p = har_src; hs.bs = hs_ld; hs.ld = (int)hs_ld; hs.C = 1; hs.len = LenMap{dF_, 600, 0}; hs.Lmax = 600 * Fmax;
@@ -961,7 +961,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
 
 void Model::infer_host(const int64_t* ids, int64_t t_stride, const int32_t* lens, int B, const float* styles,
                        const float* speeds, int n_speed, uint64_t seed, uint32_t flags, float** out,
-                       int64_t* out_lens) {
+                       int64_t* out_lens, const uint64_t* utt_seeds) {
     KX_REQUIRE(out && out_lens, "infer: null output argument");
     *out = nullptr;
     KX_REQUIRE(B >= 1, "infer: empty batch");
@@ -978,9 +978,15 @@ void Model::infer_host(const int64_t* ids, int64_t t_stride, const int32_t* lens
     int64_t* d_ids;
     float* d_styles;
     int* d_fr;
+    uint64_t* d_seeds;
+    struct SeedGuard {  // the per-utterance key pointer is valid only during this call
+        const uint64_t*& p;
+        ~SeedGuard() { p = nullptr; }
+    } seed_guard{d_utt_seeds_};
     auto planIO = [&](Arena& A, size_t audio_floats) {
         A.off = 0;
         d_ids = static_cast<int64_t*>(A.alloc((size_t)B * t_stride * 8));
+        d_seeds = static_cast<uint64_t*>(A.alloc((size_t)B * 8));
         d_styles = A.f((size_t)B * 256);
         d_fr = A.i(B);
         return A.f(audio_floats);
@@ -998,6 +1004,11 @@ void Model::infer_host(const int64_t* ids, int64_t t_stride, const int32_t* lens
         float* d_audio = planIO(arenaIO_, (size_t)B * ld);
         KX_HIP(hipMemcpyAsync(d_ids, ids, (size_t)B * t_stride * 8, hipMemcpyHostToDevice, stream_));
         KX_HIP(hipMemcpyAsync(d_styles, styles, (size_t)B * 256 * 4, hipMemcpyHostToDevice, stream_));
+        d_utt_seeds_ = nullptr;
+        if (utt_seeds) {
+            KX_HIP(hipMemcpyAsync(d_seeds, utt_seeds, (size_t)B * 8, hipMemcpyHostToDevice, stream_));
+            d_utt_seeds_ = d_seeds;
+        }
         int64_t need_ld = 0;
         try {
             infer_device(d_ids, t_stride, lens, B, d_styles, speeds, n_speed, seed, flags, d_audio, ld, d_fr, &need_ld);

@@ -40,6 +40,15 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     if _lib is not None and path is None:
         return _lib
     p = path or os.environ.get("KX_LIB") or LIB_PATH
+    # torch wheels bundle their own libamdhip64; if this library (linked against /opt/rocm's) is loaded first
+    # and torch later, the process ends up with two HIP runtimes and torch sees no GPU.  Loading torch first
+    # makes both share one runtime.  Processes that never use torch (the C++ host) are unaffected.
+    import sys
+    if "torch" not in sys.modules and os.environ.get("KX_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.exists(p):
         raise FileNotFoundError(
             f"{p} is missing: build it with `python -m kokorox_amd.build` (hipcc, gfx950). "
@@ -65,6 +74,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_profile_enable": (i32, [vp, i32]),
         "kx_profile_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "kx_profile_detail": (i32, [vp, vp, i64, C.POINTER(i64)]),
+        "kx_dispatcher_create": (vp, [vp, i32, i32, i32, cp, sz]),
+        "kx_dispatcher_submit": (i32, [vp, vp, i32, vp, f32, u64, C.POINTER(C.POINTER(f32)), C.POINTER(i64), cp, sz]),
+        "kx_dispatcher_stats": (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+        "kx_dispatcher_destroy": (None, [vp]),
         "kx_debug_tap": (i32, [vp, cp, i32, vp, i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "kx_test_conv1d": (i32, [i32, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp,
                                  i32, i32, cp, sz]),
@@ -84,7 +97,8 @@ ABI_SYMBOLS = [
     "kx_version", "kx_init", "kx_create", "kx_create_from_device_blob", "kx_destroy", "kx_last_error", "kx_infer",
     "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_set_utterance_base",
     "kx_set_conv_mode", "kx_get_conv_mode",
-    "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source",
+    "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_dispatcher_create", "kx_dispatcher_submit",
+    "kx_dispatcher_stats", "kx_dispatcher_destroy", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source",
 ]
 
 
@@ -239,6 +253,53 @@ class HipKoko:
     def _check(self, rc: int):
         if rc != 0:
             raise KokoroxHipError(rc, self._lib.kx_last_error(self._h).decode())
+
+
+class Dispatcher:
+    """Batching front of one or more HipKoko models (one per GPU): the replacement for the reference's
+    one-request-at-a-time `Mutex<Session>` (ort_koko.rs:78).  `submit` blocks and is thread-safe."""
+
+    def __init__(self, models: Sequence[HipKoko], max_batch: int = 64, max_wait_us: int = 2000):
+        self._lib = load_library()
+        self._models = list(models)  # keep them alive
+        arr = (C.c_void_p * len(self._models))(*[m._h for m in self._models])
+        err = C.create_string_buffer(256)
+        self._d = self._lib.kx_dispatcher_create(arr, len(self._models), max_batch, max_wait_us, err, len(err))
+        if not self._d:
+            raise RuntimeError(f"dispatcher: {err.value.decode()}")
+
+    def submit(self, ids: Sequence[int], style: Sequence[float], speed: float = 1.0, seed: int = 0) -> np.ndarray:
+        a = np.ascontiguousarray(ids, dtype=np.int64)
+        st = _f32(np.asarray(style, dtype=np.float32).reshape(-1))
+        if st.shape[0] != STYLE_DIM:
+            raise ValueError(f"style row must have {STYLE_DIM} floats")
+        out = C.POINTER(C.c_float)()
+        n = C.c_int64(0)
+        err = C.create_string_buffer(256)
+        rc = self._lib.kx_dispatcher_submit(self._d, _ptr(a), a.shape[0], _ptr(st), float(speed), seed, C.byref(out),
+                                            C.byref(n), err, len(err))
+        if rc != 0:
+            raise KokoroxHipError(rc, err.value.decode())
+        try:
+            return np.ctypeslib.as_array(out, shape=(max(n.value, 1),))[: n.value].copy()
+        finally:
+            self._lib.kx_free_audio(out)
+
+    def stats(self):
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._lib.kx_dispatcher_stats(self._d, C.byref(a), C.byref(b), C.byref(c))
+        return {"requests": a.value, "batches": b.value, "max_batch": c.value}
+
+    def close(self):
+        if getattr(self, "_d", None):
+            self._lib.kx_dispatcher_destroy(self._d)
+            self._d = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- stand-alone kernel hooks (tests) -----------------------------------------------------

@@ -4,6 +4,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before libkokorox_hip.so: one shared HIP runtime, see hip_koko.load_library)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
