@@ -124,6 +124,32 @@ int kx_profile_read(kx_model* m, int64_t* launches, double* total_ms, double* to
  * stride, store form, summed columns, FLOPs, milliseconds.  out = NULL returns the count only. */
 int kx_profile_detail(kx_model* m, double* out, int64_t cap_rows, int64_t* n_rows);
 
+/* ---- voice table on device + output packing -----------------------------
+ * kx_set_voice_table uploads the table that `TTSKoko::load_voices` builds (kokorox/src/tts/koko.rs:1308-1334;
+ * layout [n_voices][511][1][256] f32, row 510 zero, kokorox/src/utils/hf_cache.rs:284-309) once; requests then
+ * carry (voice id, weight) pairs instead of 256 floats.  The mix is `mix_styles` (koko.rs:1255-1306) on the
+ * GPU, bit for bit: max_mix = 1 copies row `lens[b] - 2` of the voice; otherwise the row is
+ * sum_k row_k * (weights[k] * 0.1), in order, un-normalised; entries with voice id < 0 are skipped. */
+int kx_set_voice_table(kx_model* m, const float* table, int n_voices);
+
+/* Output forms of the reference: 0 = f32 mono (ort_koko.rs:80-87), 1 = f32 stereo with every sample written
+ * twice (koko.rs:1239-1246), 2 = 16-bit PCM `(s.clamp(-1,1) * 32767) as i16` (kokorox-websocket/src/lib.rs:701-704).
+ * Packed on the GPU, so only the packed bytes cross PCIe. */
+#define KX_PACK_F32_MONO 0
+#define KX_PACK_F32_STEREO 1
+#define KX_PACK_PCM16_MONO 2
+
+/* kx_infer with device-side style lookup/mix and packed output.  *out = malloc'd bytes of the B utterances back
+ * to back (kx_free_packed); out_bytes[b] / out_samples[b] per utterance. */
+int kx_infer_voices(kx_model* m, const int64_t* ids, int64_t t_stride, const int32_t* lens, int B,
+                    const int32_t* voice_ids, const float* weights, int max_mix, const float* speeds, int n_speed,
+                    uint64_t seed, uint32_t flags, int format, void** out, int64_t* out_bytes, int64_t* out_samples);
+/* kx_infer (explicit style rows) with packed output. */
+int kx_infer_packed(kx_model* m, const int64_t* ids, int64_t t_stride, const int32_t* lens, int B, const float* styles,
+                    const float* speeds, int n_speed, uint64_t seed, uint32_t flags, int format, void** out,
+                    int64_t* out_bytes, int64_t* out_samples);
+void kx_free_packed(void* p);
+
 /* ---- request dispatcher ----------------------------------------------------
  * Replaces the reference's one-request-at-a-time `Mutex<Session>` (kokorox/src/onn/ort_koko.rs:78; callers
  * kokorox-openai/src/lib.rs:370-439, kokorox-websocket/src/lib.rs:657-668).  Any number of threads submit

@@ -133,6 +133,37 @@ int kx_infer(kx_model* m, const int64_t* ids, int64_t t_stride, const int32_t* l
 }
 
 void kx_free_audio(float* p) { free(p); }
+void kx_free_packed(void* p) { free(p); }
+
+int kx_set_voice_table(kx_model* m, const float* table, int n_voices) {
+    return guarded(m, [&](Model& M) { M.set_voice_table(table, n_voices); });
+}
+
+int kx_infer_voices(kx_model* m, const int64_t* ids, int64_t t_stride, const int32_t* lens, int B,
+                    const int32_t* voice_ids, const float* weights, int max_mix, const float* speeds, int n_speed,
+                    uint64_t seed, uint32_t flags, int format, void** out, int64_t* out_bytes, int64_t* out_samples) {
+    return guarded(m, [&](Model& M) {
+        KX_REQUIRE(voice_ids && weights, "infer_voices: null argument");
+        Model::HostCall hc;
+        hc.voice_ids = voice_ids;
+        hc.weights = weights;
+        hc.max_mix = max_mix;
+        hc.format = format;
+        M.infer_host_ex(ids, t_stride, lens, B, speeds, n_speed, seed, flags, hc, out, out_bytes, out_samples);
+    });
+}
+
+int kx_infer_packed(kx_model* m, const int64_t* ids, int64_t t_stride, const int32_t* lens, int B, const float* styles,
+                    const float* speeds, int n_speed, uint64_t seed, uint32_t flags, int format, void** out,
+                    int64_t* out_bytes, int64_t* out_samples) {
+    return guarded(m, [&](Model& M) {
+        KX_REQUIRE(styles, "infer_packed: null argument");
+        Model::HostCall hc;
+        hc.styles = styles;
+        hc.format = format;
+        M.infer_host_ex(ids, t_stride, lens, B, speeds, n_speed, seed, flags, hc, out, out_bytes, out_samples);
+    });
+}
 
 int kx_infer_device(kx_model* m, const int64_t* d_ids, int64_t t_stride, const int32_t* lens_host, int B,
                     const float* d_styles, const float* speeds_host, int n_speed, uint64_t seed, uint32_t flags,

@@ -422,6 +422,63 @@ void launch_stats_finalize(const float2* part, int tiles, int cols_per_tile, int
     KX_HIP(hipGetLastError());
 }
 
+// ---- voice table on device: style row lookup + the reference's un-normalised mix ---------------------
+// TTSKoko::mix_styles (kokorox/src/tts/koko.rs:1255-1306): single voice = copy of row `tokens_len`;
+// "a.4+b.5" = sum_k row_k * (w_k * 0.1) accumulated in order, f32, no normalisation (0.4 + 0.5 = 0.9 is used
+// as is).  Multiplies and adds are kept un-fused so the result equals the host mixer bit for bit.
+__global__ void style_mix_kernel(const float* table, int n_voices, const int* voice_ids, const float* weights,
+                                 int max_mix, const int* rows, float* styles) {
+#pragma clang fp contract(off)  // (HIP's __fmul_rn / __fadd_rn are plain * and +: without this they fuse into an FMA)
+    const int b = blockIdx.x, j = threadIdx.x;
+    const int row = rows[b];
+    const int* v = voice_ids + (long)b * max_mix;
+    const float* w = weights + (long)b * max_mix;
+    float acc = 0.f;
+    if (max_mix == 1) {
+        acc = table[((long)v[0] * 511 + row) * 256 + j];
+    } else {
+        for (int k = 0; k < max_mix; ++k) {
+            if (v[k] < 0 || v[k] >= n_voices) continue;
+            const float p = w[k] * 0.1f;
+            const float term = table[((long)v[k] * 511 + row) * 256 + j] * p;
+            acc = acc + term;
+        }
+    }
+    styles[(long)b * 256 + j] = acc;
+}
+void launch_style_mix(const float* table, int n_voices, const int* voice_ids, const float* weights, int max_mix,
+                      const int* rows, float* styles, int B, hipStream_t s) {
+    hipLaunchKernelGGL(style_mix_kernel, dim3(B), dim3(256), 0, s, table, n_voices, voice_ids, weights, max_mix, rows,
+                       styles);
+    KX_HIP(hipGetLastError());
+}
+
+// ---- output packing on device ------------------------------------------------------------------------
+// f32 stereo = every sample written twice (koko.rs:1239-1246); PCM16 = (s.clamp(-1,1) * 32767) as i16,
+// i.e. truncation toward zero, NaN -> 0 (kokorox-websocket/src/lib.rs:701-704).
+__global__ void pack_audio_kernel(const float* audio, long audio_ld, const int* frames, int format, void* out,
+                                  long out_stride_bytes) {
+    const long j = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (j >= 600L * frames[b]) return;
+    const float sv = audio[b * audio_ld + j];
+    char* ob = static_cast<char*>(out) + b * out_stride_bytes;
+    if (format == 1) {
+        reinterpret_cast<float2*>(ob)[j] = make_float2(sv, sv);
+    } else if (format == 2) {
+        const float c = fminf(fmaxf(sv, -1.0f), 1.0f);
+        reinterpret_cast<short*>(ob)[j] = (short)__float2int_rz(__fmul_rn(c, 32767.0f));
+    } else {
+        reinterpret_cast<float*>(ob)[j] = sv;
+    }
+}
+void launch_pack_audio(const float* audio, long audio_ld, const int* frames, int B, int Fmax, int format, void* out,
+                       long out_stride_bytes, hipStream_t s) {
+    hipLaunchKernelGGL(pack_audio_kernel, dim3((600 * Fmax + 255) / 256, B), dim3(256), 0, s, audio, audio_ld, frames,
+                       format, out, out_stride_bytes);
+    KX_HIP(hipGetLastError());
+}
+
 // ---- row fills / copies ---------------------------------------------------------------------
 __global__ void fill_style_rows_kernel(float* dst, long bs, int ld, int row0, const float* styles, int style_off,
                                        const int* lens) {

@@ -157,6 +157,10 @@ void launch_stats_finalize(const float2* part, int tiles, int cols_per_tile, int
 void launch_in_stats(const float* x, long bs, int ld, int C, LenMap len, int B, const float* gb, long gb_bs,
                      float* mean, float* scale, float* shift, int n_bs, hipStream_t s);
 
+void launch_style_mix(const float* table, int n_voices, const int* voice_ids, const float* weights, int max_mix,
+                      const int* rows, float* styles, int B, hipStream_t s);
+void launch_pack_audio(const float* audio, long audio_ld, const int* frames, int B, int Fmax, int format, void* out,
+                       long out_stride_bytes, hipStream_t s);
 void launch_fill_style_rows(float* dst, long bs, int ld, int row0, const float* styles, int style_off,
                             const int* lens, int B, int Tmax, hipStream_t s);
 void launch_copy_rows(const float* src, long sbs, int sld, float* dst, long dbs, int dld, int rows, LenMap len,

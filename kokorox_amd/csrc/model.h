@@ -99,6 +99,19 @@ class Model {
     void infer_host(const int64_t* ids, int64_t t_stride, const int32_t* lens, int B, const float* styles,
                     const float* speeds, int n_speed, uint64_t seed, uint32_t flags, float** out,
                     int64_t* out_lens, const uint64_t* utt_seeds = nullptr);
+    // general host entry behind kx_infer / kx_infer_voices / kx_infer_packed
+    struct HostCall {
+        const float* styles = nullptr;       // host [B][256], or
+        const int32_t* voice_ids = nullptr;  // host [B][max_mix] into the device voice table
+        const float* weights = nullptr;      // host [B][max_mix]
+        int max_mix = 0;
+        const uint64_t* utt_seeds = nullptr;
+        int format = 0;                      // 0 f32 mono, 1 f32 stereo, 2 pcm16 mono
+    };
+    void infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* lens, int B, const float* speeds,
+                       int n_speed, uint64_t seed, uint32_t flags, const HostCall& hc, void** out, int64_t* out_bytes,
+                       int64_t* out_samples);
+    void set_voice_table(const float* table, int n_voices);
     void sync();
     void set_pinned(const int32_t* pattern, int n);
     void profile_enable(bool on);
@@ -151,6 +164,8 @@ class Model {
 
     Arena arenaT_, arenaF_, arenaIO_;
     const uint64_t* d_utt_seeds_ = nullptr;  // per-utterance noise keys of the running call (dispatcher)
+    float* d_voices_ = nullptr;  // [n_voices_][511][256]
+    int n_voices_ = 0;
     int* d_pinned_ = nullptr;
     int n_pinned_ = 0;
 

@@ -959,36 +959,95 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     back(arenaF_);
 }
 
+void Model::set_voice_table(const float* table, int n_voices) {
+    KX_REQUIRE(table && n_voices >= 1 && n_voices <= 4096, "voice table: 1..4096 voices of [511][256] floats");
+    KX_HIP(hipSetDevice(device));
+    KX_HIP(hipStreamSynchronize(stream_));
+    if (d_voices_) {
+        for (auto it = owned_.begin(); it != owned_.end(); ++it)
+            if (*it == d_voices_) {
+                owned_.erase(it);
+                break;
+            }
+        KX_HIP(hipFree(d_voices_));
+        d_voices_ = nullptr;
+    }
+    const size_t n = (size_t)n_voices * 511 * 256;
+    d_voices_ = dev_alloc(n);
+    KX_HIP(hipMemcpy(d_voices_, table, n * sizeof(float), hipMemcpyHostToDevice));
+    n_voices_ = n_voices;
+}
+
 void Model::infer_host(const int64_t* ids, int64_t t_stride, const int32_t* lens, int B, const float* styles,
                        const float* speeds, int n_speed, uint64_t seed, uint32_t flags, float** out,
                        int64_t* out_lens, const uint64_t* utt_seeds) {
     KX_REQUIRE(out && out_lens, "infer: null output argument");
+    HostCall hc;
+    hc.styles = styles;
+    hc.utt_seeds = utt_seeds;
+    KX_REQUIRE(styles, "infer: null argument");
+    void* p = nullptr;
+    *out = nullptr;
+    std::vector<int64_t> bytes(B > 0 ? B : 1);
+    infer_host_ex(ids, t_stride, lens, B, speeds, n_speed, seed, flags, hc, &p, bytes.data(), out_lens);
+    *out = static_cast<float*>(p);
+}
+
+void Model::infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* lens, int B, const float* speeds,
+                          int n_speed, uint64_t seed, uint32_t flags, const HostCall& hc, void** out,
+                          int64_t* out_bytes, int64_t* out_samples) {
+    KX_REQUIRE(out && out_bytes && out_samples, "infer: null output argument");
     *out = nullptr;
     KX_REQUIRE(B >= 1, "infer: empty batch");
-    KX_REQUIRE(ids && lens && styles && speeds, "infer: null argument");
+    KX_REQUIRE(ids && lens && speeds, "infer: null argument");
+    KX_REQUIRE(hc.format >= 0 && hc.format <= 2, "infer: unknown output format");
+    const bool by_voice = hc.voice_ids != nullptr;
+    KX_REQUIRE(by_voice || hc.styles, "infer: styles or voice ids are required");
+    if (by_voice) {
+        KX_REQUIRE(d_voices_ && hc.weights && hc.max_mix >= 1 && hc.max_mix <= 16, "infer: voice table not set or bad mix");
+    }
     for (int b = 0; b < B; ++b) {
         KX_REQUIRE(lens[b] >= 1 && lens[b] <= 512 && lens[b] <= t_stride, "infer: token count must be 1..512");
         for (int t = 0; t < lens[b]; ++t) {
             const int64_t id = ids[b * t_stride + t];
             KX_REQUIRE(id >= 0 && id < 178, "infer: token id outside 0..177");
         }
+        if (by_voice) {
+            KX_REQUIRE(lens[b] >= 2, "infer: voice rows need the two 0 pads (row = tokens - 2)");
+            bool any = false;
+            for (int k = 0; k < hc.max_mix; ++k) {
+                const int v = hc.voice_ids[(size_t)b * hc.max_mix + k];
+                KX_REQUIRE(v < n_voices_, "infer: voice id outside the table");
+                any = any || v >= 0;
+            }
+            KX_REQUIRE(any && (hc.max_mix > 1 || hc.voice_ids[(size_t)b * hc.max_mix] >= 0), "infer: no voice given");
+        }
     }
     KX_HIP(hipSetDevice(device));
-    // I/O staging lives in its own arena: ids, styles, frames, audio
+    // I/O staging lives in its own arena: ids, styles, frames, noise keys, voice picks, audio, packed audio
     int64_t* d_ids;
     float* d_styles;
     int* d_fr;
     uint64_t* d_seeds;
+    int *d_vid, *d_rows;
+    float* d_w;
+    void* d_packed;
     struct SeedGuard {  // the per-utterance key pointer is valid only during this call
         const uint64_t*& p;
         ~SeedGuard() { p = nullptr; }
     } seed_guard{d_utt_seeds_};
+    const int mm = by_voice ? hc.max_mix : 1;
+    const int bytes_per_sample = hc.format == 1 ? 8 : (hc.format == 2 ? 2 : 4);
     auto planIO = [&](Arena& A, size_t audio_floats) {
         A.off = 0;
         d_ids = static_cast<int64_t*>(A.alloc((size_t)B * t_stride * 8));
         d_seeds = static_cast<uint64_t*>(A.alloc((size_t)B * 8));
         d_styles = A.f((size_t)B * 256);
         d_fr = A.i(B);
+        d_vid = A.i((size_t)B * mm);
+        d_rows = A.i(B);
+        d_w = A.f((size_t)B * mm);
+        d_packed = hc.format == 0 ? nullptr : A.alloc(audio_floats * bytes_per_sample);
         return A.f(audio_floats);
     };
     // worst case length is 50 frames per token; start from a typical 8 and retry once if short
@@ -1003,10 +1062,19 @@ void Model::infer_host(const int64_t* ids, int64_t t_stride, const int32_t* lens
         ensure_arena(arenaIO_, need);
         float* d_audio = planIO(arenaIO_, (size_t)B * ld);
         KX_HIP(hipMemcpyAsync(d_ids, ids, (size_t)B * t_stride * 8, hipMemcpyHostToDevice, stream_));
-        KX_HIP(hipMemcpyAsync(d_styles, styles, (size_t)B * 256 * 4, hipMemcpyHostToDevice, stream_));
+        if (by_voice) {
+            std::vector<int> rows(B);
+            for (int b = 0; b < B; ++b) rows[b] = lens[b] - 2;  // tokens before the 0 padding (koko.rs:1161-1166)
+            KX_HIP(hipMemcpyAsync(d_vid, hc.voice_ids, (size_t)B * mm * 4, hipMemcpyHostToDevice, stream_));
+            KX_HIP(hipMemcpyAsync(d_w, hc.weights, (size_t)B * mm * 4, hipMemcpyHostToDevice, stream_));
+            KX_HIP(hipMemcpy(d_rows, rows.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+            launch_style_mix(d_voices_, n_voices_, d_vid, d_w, mm, d_rows, d_styles, B, stream_);
+        } else {
+            KX_HIP(hipMemcpyAsync(d_styles, hc.styles, (size_t)B * 256 * 4, hipMemcpyHostToDevice, stream_));
+        }
         d_utt_seeds_ = nullptr;
-        if (utt_seeds) {
-            KX_HIP(hipMemcpyAsync(d_seeds, utt_seeds, (size_t)B * 8, hipMemcpyHostToDevice, stream_));
+        if (hc.utt_seeds) {
+            KX_HIP(hipMemcpyAsync(d_seeds, hc.utt_seeds, (size_t)B * 8, hipMemcpyHostToDevice, stream_));
             d_utt_seeds_ = d_seeds;
         }
         int64_t need_ld = 0;
@@ -1019,22 +1087,29 @@ void Model::infer_host(const int64_t* ids, int64_t t_stride, const int32_t* lens
             }
             throw;
         }
+        const char* src = reinterpret_cast<const char*>(d_audio);
+        if (hc.format != 0) {
+            launch_pack_audio(d_audio, ld, dF_, B, Fmax_, hc.format, d_packed, ld * bytes_per_sample, stream_);
+            src = static_cast<const char*>(d_packed);
+        }
         KX_HIP(hipStreamSynchronize(stream_));
         int64_t total = 0;
         for (int b = 0; b < B; ++b) {
-            out_lens[b] = (int64_t)600 * hF_[b];
-            total += out_lens[b];
+            out_samples[b] = (int64_t)600 * hF_[b];
+            out_bytes[b] = out_samples[b] * bytes_per_sample;
+            total += out_bytes[b];
         }
-        float* host = static_cast<float*>(malloc((size_t)(total > 0 ? total : 1) * sizeof(float)));
+        char* host = static_cast<char*>(malloc((size_t)(total > 0 ? total : 1)));
         if (!host) throw Error(3, "infer: out of host memory");
         int64_t o = 0;
         for (int b = 0; b < B; ++b) {
-            hipError_t e = hipMemcpy(host + o, d_audio + (int64_t)b * ld, (size_t)out_lens[b] * 4, hipMemcpyDeviceToHost);
+            hipError_t e = hipMemcpy(host + o, src + (int64_t)b * ld * bytes_per_sample, (size_t)out_bytes[b],
+                                     hipMemcpyDeviceToHost);
             if (e != hipSuccess) {
                 free(host);
                 throw Error(3, std::string("infer: D2H copy failed: ") + hipGetErrorString(e));
             }
-            o += out_lens[b];
+            o += out_bytes[b];
         }
         *out = host;
         return;

@@ -20,6 +20,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libkokorox_hip.so")
 
+PACK_F32_MONO, PACK_F32_STEREO, PACK_PCM16_MONO = 0, 1, 2
 KX_FLAG_NOISE_OFF = 1
 KX_FLAG_TAPS = 2
 STYLE_DIM = 256
@@ -74,6 +75,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_profile_enable": (i32, [vp, i32]),
         "kx_profile_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "kx_profile_detail": (i32, [vp, vp, i64, C.POINTER(i64)]),
+        "kx_set_voice_table": (i32, [vp, vp, i32]),
+        "kx_infer_voices": (i32, [vp, vp, i64, vp, i32, vp, vp, i32, vp, i32, u64, u32, i32, C.POINTER(vp), vp, vp]),
+        "kx_infer_packed": (i32, [vp, vp, i64, vp, i32, vp, vp, i32, u64, u32, i32, C.POINTER(vp), vp, vp]),
+        "kx_free_packed": (None, [vp]),
         "kx_dispatcher_create": (vp, [vp, i32, i32, i32, cp, sz]),
         "kx_dispatcher_submit": (i32, [vp, vp, i32, vp, f32, u64, C.POINTER(C.POINTER(f32)), C.POINTER(i64), cp, sz]),
         "kx_dispatcher_stats": (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
@@ -97,7 +102,8 @@ ABI_SYMBOLS = [
     "kx_version", "kx_init", "kx_create", "kx_create_from_device_blob", "kx_destroy", "kx_last_error", "kx_infer",
     "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_set_utterance_base",
     "kx_set_conv_mode", "kx_get_conv_mode",
-    "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_dispatcher_create", "kx_dispatcher_submit",
+    "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_set_voice_table", "kx_infer_voices",
+    "kx_infer_packed", "kx_free_packed", "kx_dispatcher_create", "kx_dispatcher_submit",
     "kx_dispatcher_stats", "kx_dispatcher_destroy", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source",
 ]
 
@@ -181,6 +187,59 @@ class HipKoko:
             res.append(flat[o: o + int(out_lens[b])])
             o += int(out_lens[b])
         return res
+
+    # -- device voice table, packed output -----------------------------
+    def set_voice_table(self, table: np.ndarray):
+        """table [n_voices, 511, 1, 256] (or [n, 511, 256]) as built by load_voices / hf_cache.rs:284-309."""
+        t = _f32(np.asarray(table, dtype=np.float32).reshape(-1, 511, 256))
+        self._check(self._lib.kx_set_voice_table(self._h, _ptr(t), t.shape[0]))
+
+    def _unpack(self, out, nbytes, nsamp, B, fmt):
+        total = int(nbytes[:B].sum())
+        raw = C.string_at(out, total) if total else b""
+        self._lib.kx_free_packed(out)
+        res, o = [], 0
+        dt = np.int16 if fmt == PACK_PCM16_MONO else np.float32
+        for b in range(B):
+            a = np.frombuffer(raw, dtype=dt, count=int(nbytes[b]) // np.dtype(dt).itemsize, offset=o).copy()
+            res.append(a.reshape(-1, 2) if fmt == PACK_F32_STEREO else a)
+            o += int(nbytes[b])
+        return res
+
+    def _ids_lens(self, tokens):
+        B = len(tokens)
+        lens = np.array([len(t) for t in tokens], dtype=np.int32)
+        ids = np.zeros((B, max(int(lens.max()), 1)), dtype=np.int64)
+        for b, t in enumerate(tokens):
+            ids[b, : len(t)] = np.asarray(t, dtype=np.int64)
+        return ids, lens
+
+    def infer_voices(self, tokens, voice_ids, weights, speeds=(1.0,), seed: int = 0, flags: int = 0,
+                     fmt: int = 0) -> List[np.ndarray]:
+        """Style rows are looked up / mixed on the GPU: voice_ids [B, max_mix] (-1 = unused), weights [B, max_mix]
+        (the number after the dot in "af_sky.4+af_nicole.5"); max_mix == 1 is the single-voice copy."""
+        ids, lens = self._ids_lens(tokens)
+        B = len(tokens)
+        v = np.ascontiguousarray(np.asarray(voice_ids, dtype=np.int32).reshape(B, -1))
+        w = _f32(np.asarray(weights, dtype=np.float32).reshape(B, -1))
+        sp = _f32(np.asarray(speeds, dtype=np.float32).reshape(-1))
+        out = C.c_void_p()
+        nbytes, nsamp = np.zeros(B, np.int64), np.zeros(B, np.int64)
+        self._check(self._lib.kx_infer_voices(self._h, _ptr(ids), ids.shape[1], _ptr(lens), B, _ptr(v), _ptr(w),
+                                              v.shape[1], _ptr(sp), sp.shape[0], seed, flags, fmt, C.byref(out),
+                                              _ptr(nbytes), _ptr(nsamp)))
+        return self._unpack(out, nbytes, nsamp, B, fmt)
+
+    def infer_packed(self, tokens, styles, speeds=(1.0,), seed: int = 0, flags: int = 0, fmt: int = 0):
+        ids, lens = self._ids_lens(tokens)
+        B = len(tokens)
+        st = _f32(np.asarray(styles, dtype=np.float32).reshape(B, STYLE_DIM))
+        sp = _f32(np.asarray(speeds, dtype=np.float32).reshape(-1))
+        out = C.c_void_p()
+        nbytes, nsamp = np.zeros(B, np.int64), np.zeros(B, np.int64)
+        self._check(self._lib.kx_infer_packed(self._h, _ptr(ids), ids.shape[1], _ptr(lens), B, _ptr(st), _ptr(sp),
+                                              sp.shape[0], seed, flags, fmt, C.byref(out), _ptr(nbytes), _ptr(nsamp)))
+        return self._unpack(out, nbytes, nsamp, B, fmt)
 
     def infer_device(self, d_ids: int, t_stride: int, lens_host: np.ndarray, d_styles: int, speeds_host: np.ndarray,
                      d_audio: int, audio_ld: int, d_frames: int, seed: int = 0, flags: int = 0) -> int:
