@@ -118,3 +118,78 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dp, f), encoding="utf-8").read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def _fake_upstream_checkpoint(tensors, rng):
+    """Synthetic weights dressed as the upstream checkpoint: nested per module, 'module.' prefixes,
+    weight-norm (g, v) pairs for the convs, plus tensors the forward never reads."""
+    nested = {}
+    for name, a in tensors.items():
+        top, key = name.split(".", 1)
+        sd = nested.setdefault(top, {})
+        is_conv = key.endswith(".weight") and a.ndim == 3 and "embeddings" not in key and top in (
+            "predictor", "text_encoder", "decoder") and "alpha" not in key and "noise_convs" not in key and \
+            "m_source" not in key and "_proj" not in key
+        if is_conv:
+            v = (a.astype(np.float64) * rng.uniform(0.5, 2.0, size=(a.shape[0], 1, 1))).astype(np.float32)
+            g = np.sqrt((a.astype(np.float64).reshape(a.shape[0], -1) ** 2).sum(1)).reshape(-1, 1, 1).astype(np.float32)
+            sd["module." + key[:-7] + ".weight_g"] = g
+            sd["module." + key[:-7] + ".weight_v"] = v
+        else:
+            sd["module." + key] = a
+    nested["bert"]["module.embeddings.position_ids"] = np.arange(512, dtype=np.float32)[None]
+    nested["bert"]["module.pooler.weight"] = np.zeros((768, 768), np.float32)
+    nested["bert"]["module.pooler.bias"] = np.zeros(768, np.float32)
+    nested["decoder"]["module.encode.norm1.norm.weight"] = np.ones(514, np.float32)
+    nested["decoder"]["module.encode.norm1.norm.bias"] = np.zeros(514, np.float32)
+    return nested
+
+
+def test_importer_folds_weight_norm_and_matches_spec(tmp_path):
+    """an upstream-style checkpoint becomes the blob kx_create reads."""
+    from kokorox_amd import importer as I
+    rng = np.random.default_rng(0)
+    spec = W.tensor_spec()
+    # small stand-in values with the real shapes (only a slice of the big tensors is random: speed)
+    tensors = {}
+    for name, (shape, _) in spec.items():
+        a = np.zeros(shape, np.float32)
+        a.reshape(-1)[: min(a.size, 4096)] = rng.standard_normal(min(a.size, 4096)).astype(np.float32)
+        a.reshape(-1)[-1] = 1.0
+        if a.ndim == 3:  # keep every conv row non-zero so its weight-norm is defined
+            a[:, 0, 0] += 0.5
+        tensors[name] = a
+    ckpt = _fake_upstream_checkpoint(tensors, rng)
+    out = I.to_blob_tensors(ckpt)
+    assert list(out) == list(spec)
+    for name in ("decoder.generator.resblocks.3.convs1.1.weight", "text_encoder.cnn.0.0.weight",
+                 "decoder.generator.ups.0.weight", "predictor.lstm.weight_hh_l0_reverse", "bert_encoder.bias"):
+        np.testing.assert_allclose(out[name], tensors[name], rtol=2e-6, atol=1e-7)
+    p = str(tmp_path / "imported.kxw")
+    W.write_blob(p, out)
+    back = W.read_blob(p)
+    np.testing.assert_array_equal(np.asarray(back["decoder.generator.conv_post.bias"]), out["decoder.generator.conv_post.bias"])
+    # strictness: a missing tensor, a wrong shape and an unknown tensor are all errors
+    bad = {k: dict(v) for k, v in ckpt.items()}
+    del bad["bert_encoder"]["module.bias"]
+    with pytest.raises(KeyError):
+        I.to_blob_tensors(bad)
+    bad = {k: dict(v) for k, v in ckpt.items()}
+    bad["predictor"]["module.mystery.weight"] = np.zeros(3, np.float32)
+    with pytest.raises(KeyError):
+        I.to_blob_tensors(bad)
+    bad = {k: dict(v) for k, v in ckpt.items()}
+    bad["bert_encoder"]["module.weight"] = np.zeros((512, 767), np.float32)
+    with pytest.raises(ValueError):
+        I.to_blob_tensors(bad)
+
+
+def test_importer_reads_safetensors(tmp_path):
+    from safetensors.numpy import save_file
+    from kokorox_amd import importer as I
+    a = {"x.weight": np.arange(6, dtype=np.float32).reshape(2, 3), "y.bias": np.ones(4, np.float16)}
+    p = str(tmp_path / "t.safetensors")
+    save_file(a, p)
+    r = I.read_safetensors(p)
+    np.testing.assert_array_equal(r["x.weight"], a["x.weight"])
+    np.testing.assert_array_equal(r["y.bias"], a["y.bias"].astype(np.float32))
