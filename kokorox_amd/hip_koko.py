@@ -40,6 +40,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
+    import sys
     p = path or os.environ.get("KX_LIB") or LIB_PATH
     # torch wheels bundle their own libamdhip64; if this library (linked against /opt/rocm's) is loaded first
     # and torch later, the process ends up with two HIP runtimes and torch sees no GPU.  Loading torch first
@@ -50,6 +51,13 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
             import torch  # noqa: F401
         except Exception:
             pass
+    if not os.path.exists(p) and p == LIB_PATH and os.environ.get("KX_NO_AUTOBUILD") != "1":
+        # the prebuilt library normally travels with the tree; as a last resort build it here (hipcc, ~2-3 min)
+        try:
+            from . import build as _build
+            _build.build_library(verbose=True)
+        except Exception as e:  # fall through to the loud error below
+            print(f"kokorox_amd: building libkokorox_hip.so failed: {e}", file=sys.stderr)
     if not os.path.exists(p):
         raise FileNotFoundError(
             f"{p} is missing: build it with `python -m kokorox_amd.build` (hipcc, gfx950). "
