@@ -74,13 +74,16 @@ __device__ __forceinline__ void glds16(const uint4* gsrc_lane, uint4* lds_wave_b
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int ACT, int TK, bool PF>
+template <int BM, int BN, int WM, int WN, int ACT, int TK, bool PF, int VT>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : ((BM / WM / 32) * (BN / WN / 32) > 6 ? 2 : 3))
 void conv1d_f16x3_kernel(const ConvArgs a) {
     constexpr int MT = BM / WM / 32;
     constexpr int NT = BN / WN / 32;
     constexpr int NWV = WM * WN;  // waves per workgroup: 4, or 8 (same tile, half the registers per wave)
     static_assert((NWV == 4 || NWV == 8) && MT >= 1 && NT >= 1, "4 or 8 waves per workgroup");
+    // VT > 1 ("virtual taps", k = 1 GEMMs only): VT consecutive 16-channel chunks are staged together and walked
+    // as VT taps of one super-chunk, so one barrier pair feeds VT x more matrix work
+    static_assert(VT == 1 || (VT <= TK && PF), "virtual taps need TK >= VT and the prefetching build");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
 
     const int tid = threadIdx.x;
@@ -115,9 +118,10 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int n_chunks = a.n_chunks16;
-    const int n_pieces = (K + TK - 1) / TK;
-    const uint4* wbase = reinterpret_cast<const uint4*>(a.w16) + (long)ct * n_chunks * K * tap_units;
+    const int n_chunks16 = a.n_chunks16;
+    const int n_chunks = (VT == 1) ? n_chunks16 : (n_chunks16 + VT - 1) / VT;  // (super-)chunks walked below
+    const int n_pieces = (VT == 1) ? (K + TK - 1) / TK : 1;
+    const uint4* wbase = reinterpret_cast<const uint4*>(a.w16) + (long)ct * n_chunks16 * K * tap_units;
     const float* xb = a.x + (long)b * a.x_bs;
     const int p0 = t0 * stride - a.pad;
     const bool has_norm = a.nmean != nullptr;
@@ -127,8 +131,12 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
     // asynchronous copy of weight piece (chunk ch, piece pc) into Wbuf[buf]: whole 1-KiB segments per wave
     auto issue_piece = [&](int ch, int pc, int buf) {
         const int tp = pc * TK;
-        const int taps = (K - tp) < TK ? (K - tp) : TK;
+        int taps = (K - tp) < TK ? (K - tp) : TK;
         const uint4* src = wbase + ((long)ch * K + tp) * tap_units;
+        if (VT > 1) {  // k = 1: chunk16 c sits at c * tap_units, a super-chunk is VT of them back to back
+            taps = (n_chunks16 - ch * VT) < VT ? (n_chunks16 - ch * VT) : VT;
+            src = wbase + (long)ch * VT * tap_units;
+        }
         uint4* dst = Wbuf + buf * piece_units;
         const int nseg = taps * tap_units / 64;
         if (a.dbg & 2) return;
@@ -140,9 +148,9 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
     // packed hi pair and one packed lo pair into the [time][8 ch] image.  With PF the raw values of the NEXT
     // chunk are loaded into registers before the MFMA loop of the current one (their latency hides behind
     // the matrix work) and are transformed + written after it.
-    constexpr int NI = 5;  // PF needs XW <= 64 * NI (the launcher checks)
-    constexpr int NH = 8 / NWV;  // channel pairs staged per wave
-    float raw[NH][NI][2];
+    constexpr int NI = (VT > 1) ? 2 : 5;  // PF needs XW <= 64 * NI (the launcher checks)
+    constexpr int NH = 8 / NWV;            // channel pairs staged per wave
+    float raw[VT][NH][NI][2];
     // per-lane element offsets of this lane's NI window columns (they do not depend on the chunk)
     int xoff[NI];
     unsigned okmask = 0;
@@ -165,20 +173,27 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
         }
     }
     const float* xbase = merged ? a.x : xb;
-    auto load_raw = [&](int ch) {
+    auto load_raw = [&](int sc) {
 #pragma unroll
-        for (int half = 0; half < NH; ++half) {
-            const int cA = ch * CK16 + 2 * (wave + NWV * half), cB = cA + 1;
-            const float* rowA = xbase + (long)(cA < a.Cin ? cA : 0) * a.x_ld;
-            const float* rowB = xbase + (long)(cB < a.Cin ? cB : 0) * a.x_ld;
+        for (int vt = 0; vt < VT; ++vt) {
+            const int ch = sc * VT + vt;  // 16-channel chunk staged as virtual tap vt
 #pragma unroll
-            for (int it = 0; it < NI; ++it) {
-                raw[half][it][0] = rowA[xoff[it]];
-                raw[half][it][1] = rowB[xoff[it]];
+            for (int half = 0; half < NH; ++half) {
+                const int cA = ch * CK16 + 2 * (wave + NWV * half), cB = cA + 1;
+                const float* rowA = xbase + (long)(cA < a.Cin ? cA : 0) * a.x_ld;
+                const float* rowB = xbase + (long)(cB < a.Cin ? cB : 0) * a.x_ld;
+#pragma unroll
+                for (int it = 0; it < NI; ++it) {
+                    raw[vt][half][it][0] = rowA[xoff[it]];
+                    raw[vt][half][it][1] = rowB[xoff[it]];
+                }
             }
         }
     };
-    auto stage_chunk = [&](int ch, bool from_raw) {
+    auto stage_chunk = [&](int sc, bool from_raw) {
+#pragma unroll
+      for (int vt = 0; vt < VT; ++vt) {
+        const int ch = sc * VT + vt;
 #pragma unroll
         for (int half = 0; half < NH; ++half) {
             const int pr = wave + NWV * half;  // pair index 0..7 inside the 16-channel chunk
@@ -199,8 +214,8 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
             const float* rowB = xbase + (long)cBc * a.x_ld;
             // dword index of (hi image, octet g, column 0, channel slot j): ((0*2+g)*XWp)*4 + j/2
             const int g = pr >> 2, jw = pr & 3;
-            unsigned* dst_hi = Xs32 + ((0 * 2 + g) * XWp) * 4 + jw;
-            unsigned* dst_lo = Xs32 + ((1 * 2 + g) * XWp) * 4 + jw;
+            unsigned* dst_hi = Xs32 + ((vt * 4 + 0 * 2 + g) * XWp) * 4 + jw;
+            unsigned* dst_lo = Xs32 + ((vt * 4 + 1 * 2 + g) * XWp) * 4 + jw;
             auto emit = [&](int u, float xA, float xB, bool pok) {
                 float yA = in_act<ACT>((xA - mA) * sA + hA, a.slope, aA, iA);
                 float yB = in_act<ACT>((xB - mB) * sB + hB, a.slope, aB, iB);
@@ -215,7 +230,7 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int it = 0; it < NI; ++it) {
                     const int u = lane + 64 * it;
-                    if (u < XW) emit(u, raw[half][it][0], raw[half][it][1], ((okmask >> it) & 1u) != 0u);
+                    if (u < XW) emit(u, raw[vt][half][it][0], raw[vt][half][it][1], ((okmask >> it) & 1u) != 0u);
                 }
             } else {
                 if (PF) {  // first chunk of the prefetching build: same hoisted offsets, loads issued here
@@ -234,6 +249,7 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
                 }
             }
         }
+      }
     };
 
     // Co-resident workgroups of one CU start together and would stay in lockstep (staging with staging,
@@ -265,7 +281,8 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
             else if (more)
                 issue_piece(ch + 1, 0, cur ^ 1);
             const int tp = pc * TK;
-            const int taps = (K - tp) < TK ? (K - tp) : TK;
+            int taps = (K - tp) < TK ? (K - tp) : TK;
+            if (VT > 1) taps = (n_chunks16 - ch * VT) < VT ? (n_chunks16 - ch * VT) : VT;
             const uint4* Wp = Wbuf + cur * piece_units;
             for (int tt = 0; tt < ((a.dbg & 4) ? 0 : taps); ++tt) {
                 const int tap = tp + tt;
@@ -276,7 +293,8 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
                     ah[mt] = *reinterpret_cast<const half8*>(&wt[mt * 32]);
                     al_[mt] = *reinterpret_cast<const half8*>(&wt[2 * BM + mt * 32]);
                 }
-                const uint4* xt = Xs + h * XWp + (wn * (NT * 32) + r) * stride + tap * dil;
+                const uint4* xt = (VT > 1) ? Xs + (tt * 4 + h) * XWp + (wn * (NT * 32) + r) * stride
+                                           : Xs + h * XWp + (wn * (NT * 32) + r) * stride + tap * dil;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     bh[nt] = *reinterpret_cast<const half8*>(&xt[nt * 32 * stride]);
@@ -291,8 +309,16 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
                     }
             }
-            __syncthreads();  // everyone is done with Wbuf[cur] (and with Xs after the last piece);
-            cur ^= 1;         // the prefetched piece has landed
+            // Everyone must be done with Wbuf[cur] (and with Xs after the last piece).  After the last piece of a
+            // chunk a raw barrier with lgkmcnt(0) only is enough: the transform of the next chunk follows, and the
+            // weight piece that was just issued stays in flight across it (a __syncthreads() would drain vmcnt and
+            // expose the copy latency right behind a short MFMA burst); the full barrier after the transform
+            // retires it.  Between pieces of one chunk the next piece must have landed: full barrier.
+            if (pc + 1 == n_pieces && more)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else
+                __syncthreads();
+            cur ^= 1;
         }
         if (more) {
             unsigned long long ta = 0, tb = 0;
@@ -330,14 +356,15 @@ static int env_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-template <int BM, int BN, int WM, int WN, int ACT, int TK, bool PF>
+template <int BM, int BN, int WM, int WN, int ACT, int TK, bool PF, int VT = 1>
 static void launch_inst16_pf(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
     static size_t lds_limit = 64 * 1024;  // raise the dynamic-LDS limit only as far as a launch needs
-    auto kern = conv1d_f16x3_kernel<BM, BN, WM, WN, ACT, TK, PF>;
+    auto kern = conv1d_f16x3_kernel<BM, BN, WM, WN, ACT, TK, PF, VT>;
     const int XW = (BN - 1) * a.stride + (a.K - 1) * a.dil + 1;
     const int XWp = (XW + 3) & ~3;
-    const size_t lds = 16 * ((size_t)2 * TK * 4 * BM + (size_t)4 * XWp);
+    const size_t lds = 16 * ((size_t)2 * TK * 4 * BM + (size_t)VT * 4 * XWp);
     KX_REQUIRE(lds <= 160 * 1024, "conv1d f16x3: LDS tile too large for this k/stride");
+    KX_REQUIRE(VT == 1 || (a.K == 1 && a.stride == 1 && XW <= 128), "conv1d f16x3: virtual taps need a k=1 GEMM");
     if (lds > lds_limit) {
         KX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_limit = lds;
@@ -395,7 +422,13 @@ void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStre
     if (BM == 128) {
         // (an 8-wave x 128-register form of the 128x256 tile was tried: it spills and is 6 % slower)
         // (also tried: a 128x192 tile for 3 workgroups per CU: the 168-register cap spills in the main loop, 1.7x slower)
-        if (conv16_pick_bn(BM, max_cols) == 128)
+        static const int vt_env = env_int("KX_VT", 1);
+        if (vt_env && a.K == 1 && a.stride == 1 && !a.stat_part && !a.in_up2 && a.n_chunks16 >= 3 && a.act != ACT_SNAKE) {
+            if (a.act == ACT_LEAKY)
+                launch_inst16_pf<128, 128, 2, 2, ACT_LEAKY, 3, true, 3>(a, B, max_cols, s);
+            else
+                launch_inst16_pf<128, 128, 2, 2, ACT_NONE, 3, true, 3>(a, B, max_cols, s);
+        } else if (conv16_pick_bn(BM, max_cols) == 128)
             launch_inst16<128, 128, 2, 2>(a, B, max_cols, s);
         else
             launch_inst16<128, 256, 2, 2>(a, B, max_cols, s);

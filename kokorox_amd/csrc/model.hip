@@ -423,8 +423,10 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     static bool stamped = false;
     unsigned long long* d_stamps = nullptr;
     long n_wg = 0;
-    if (stamp_path && !stamped && f16 && w.K == 11 && w.rows == 128 && B_ >= 8) {
-        n_wg = (long)((max_cols + 255) / 256) * B_;
+    static const int stamp_rows = getenv("KX_STAMP_ROWS") ? atoi(getenv("KX_STAMP_ROWS")) : 128;
+    static const int stamp_k = getenv("KX_STAMP_K") ? atoi(getenv("KX_STAMP_K")) : 11;
+    if (stamp_path && !stamped && f16 && w.K == stamp_k && w.rows == stamp_rows && B_ >= 8) {
+        n_wg = (long)((max_cols + 127) / 128) * ((w.rows + 127) / 128) * (a.merge_T > 0 ? 1 : B_);
         KX_HIP(hipMalloc((void**)&d_stamps, n_wg * 64));
         KX_HIP(hipMemsetAsync(d_stamps, 0, n_wg * 64, stream_));
         a.stamps = d_stamps;

@@ -1,5 +1,5 @@
-for cfg in "KX_BN=0 KX_TK=3" "KX_BN=192 KX_TK=2" "KX_BN=192 KX_TK=2 KX_PF=0" "KX_BN=192 KX_TK=1"; do
-  echo "== $cfg"
-  env $cfg timeout -k 10 200 python bench.py --steps 3 --warmup 1 --cpu-utts 0 --free-run 0 --detail gpurun_out/var.txt 2>&1 | grep -E "timed"
-  head -6 gpurun_out/var.txt | tail -5
+for i in 1; do
+  timeout -k 10 200 python bench.py --steps 3 --warmup 1 --cpu-utts 0 --free-run 0 --detail gpurun_out/var.txt 2>&1 | grep -E "timed"
+  head -12 gpurun_out/var.txt; grep -E "^ *(2304|2048|768) +[0-9]+ +1 " gpurun_out/var.txt | head -5
+  timeout -k 10 200 python bench.py --steps 20 --warmup 3 --batch 1 --cpu-utts 0 --free-run 0 2>&1 | grep -E "timed"
 done
