@@ -30,104 +30,186 @@ __device__ __forceinline__ float half_wave_sum(float x) {
     return x + __shfl_xor(x, 16);
 }
 
-// acc scale: the f16x3 path carries the 2^ws weight pre-scale in its accumulators
-// read-modify-write store of one wave's tile (channel-major or time-major), EB rows per load batch
-template <int MT, int NT, int EB, bool ACCUM>
+// v / d for a launch-constant divisor, rd = 1 / d: one Newton step on the product makes the quotient correctly
+// rounded except in rare double-rounding cases (<= 1 ulp), at 3 VALU instead of the ~10 of a full division
+__device__ __forceinline__ float div_const(float v, float d, float rd) {
+    const float q = v * rd;
+    return fmaf(fmaf(-q, d, v), rd, q);
+}
+
+// raw buffer access: address = descriptor base + per-lane byte offset (VGPR) + wave-uniform byte offset (SGPR),
+// one instruction per access and no 64-bit address arithmetic on the vector unit
+using buf_rsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ buf_rsrc make_buf(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);  // raw, 4 GiB window
+}
+__device__ __forceinline__ float buf_load(buf_rsrc rs, unsigned lane_bytes, unsigned uniform_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane_bytes, uniform_bytes, 0));
+}
+__device__ __forceinline__ void buf_store(buf_rsrc rs, unsigned lane_bytes, unsigned uniform_bytes, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, lane_bytes, uniform_bytes, 0);
+}
+
+// Store of one wave's MT x NT block of 32x32 accumulator tiles, channel-major or time-major, with bias, residual,
+// accumulate, scale / divide, gelu_new and the fused InstanceNorm partial sums.  The accumulators of the f16x3
+// path carry the 2^ws weight pre-scale (acc_scale undoes it).
+//   FULL  : the block lies wholly inside [0, Cout) x [0, ncols): no predicates at all (the common case).
+//   !FULL : edge blocks; every store is predicated, load rows / columns are clamped.
+// Addressing: one buffer descriptor per tensor and utterance, a per-lane byte offset that does not depend on the
+// row, and a wave-uniform row term in a scalar register (FULL; the MFMA C/D map puts row + 4 in the upper
+// half-wave, which is folded into the lane offset).  Offsets are 32-bit: a lane never reaches past its own
+// utterance's tensor (merged mode: the one token-axis tensor), which the launchers keep below 4 GiB.
+//   LOADS : 0 = nothing to read back, 1 = residual, 2 = residual + accumulate into y, 3 = decided at run time
+//           (edge blocks only; the compile-time forms keep the common path free of per-row branches)
+template <int MT, int NT, int EB, int LOADS, bool FULL, bool GELU>
 __device__ __forceinline__ void conv_store_rmw(const ConvArgs& a, f32x16 (&acc)[MT][NT], float acc_scale, int b,
                                                int row0, int col0, int r, int h, int ncols, int stat_slot) {
-    {
-        // Latency-bound read-modify-write of the tile: issue the residual / accumulate loads of 8 rows x NT
-        // columns back to back (addresses clamped so the loads need no branches), then combine and store.
-        const bool tmaj = a.store == ST_TMAJOR;
-        const bool has_res = a.resid != nullptr && !tmaj, has_bias = a.bias != nullptr;
-        constexpr bool accum = ACCUM;
-        const bool gelu = a.epi == EPI_GELU_NEW, do_div = a.out_div != 1.0f;
-        const int cmax = ncols - 1, rmax = a.Cout - 1;
-        // per-column element offsets (without the row term); merged mode maps column -> (utterance, t)
-        long ycol[NT], rcol[NT];
-        bool cok[NT];
+    const bool tmaj = a.store == ST_TMAJOR;
+    const bool has_bias = a.bias != nullptr;
+    const bool has_res = LOADS == 3 ? (a.resid != nullptr && !tmaj) : (LOADS >= 1);
+    const bool accum = LOADS == 3 ? (a.accum != 0 && !tmaj) : (LOADS == 2);
+    constexpr bool ACCUM = LOADS >= 2;  // (whether the y read-back buffers exist)
+    const int cmax = ncols - 1, rmax = a.Cout - 1;
+    const bool merged = a.merge_T > 0;
+    const unsigned yrs = 4u * (tmaj ? 1u : (unsigned)a.y_ld);  // row strides in bytes
+    const unsigned rrs = 4u * (unsigned)a.r_ld;
+    const buf_rsrc ybuf = make_buf(a.y + (merged ? 0 : (long)b * a.y_bs));
+    const buf_rsrc rbuf = make_buf(has_res ? a.resid + (merged ? 0 : (long)b * a.r_bs) : a.y);
+    // bias of the wave's MT * 32 <= 64 rows: one value per lane, handed out below with v_readlane
+    const int brow = row0 + r + 32 * h;
+    const float bias_lane = has_bias ? a.bias[brow < rmax ? brow : rmax] : 0.f;
+    unsigned yoff[NT], roff[NT];
+    bool cok[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = col0 + nt * 32 + r;
-            cok[nt] = col < ncols;
-            const int cc = col < cmax ? col : cmax;
-            int bb = b, tt = cc;
-            if (a.merge_T > 0) {
-                bb = cc / a.merge_T;
-                tt = cc - bb * a.merge_T;
-            }
-            ycol[nt] = (long)bb * a.y_bs + (tmaj ? (long)tt * a.y_ld : (long)tt);
-            rcol[nt] = (long)bb * a.r_bs + tt;
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = col0 + nt * 32 + r;
+        cok[nt] = FULL || col < ncols;
+        const int cc = FULL ? col : (col < cmax ? col : cmax);
+        int bb = 0, tt = cc;
+        if (merged) {
+            bb = cc / a.merge_T;
+            tt = cc - bb * a.merge_T;
         }
-        const long yrs = tmaj ? 1 : a.y_ld;  // row stride of the output
+        yoff[nt] = 4u * ((unsigned)((long)bb * a.y_bs) + (tmaj ? (unsigned)tt * (unsigned)a.y_ld : (unsigned)tt)) +
+                   (FULL ? (unsigned)(4 * h) * yrs : 0u);
+        roff[nt] = 4u * ((unsigned)((long)bb * a.r_bs) + (unsigned)tt) + (FULL ? (unsigned)(4 * h) * rrs : 0u);
+    }
+    // row of the h = 0 lanes of accumulator register e in tile mt (wave-uniform); upper half-wave: + 4
+    auto row_of = [&](int mt, int e) { return row0 + mt * 32 + (e & 3) + 8 * (e >> 2); };
+    // FULL: the half-wave's 4-row step is already in the lane offsets, the row term is wave-uniform (scalar).
+    // !FULL: per-lane row, clamped to the last valid one (loads stay in bounds, stores are masked).
+    auto row_term = [&](int rowu, unsigned stride_bytes) -> unsigned {
+        if (FULL) return (unsigned)rowu * stride_bytes;
+        const int rl = rowu + 4 * h;
+        return (unsigned)(rl < rmax ? rl : rmax) * stride_bytes;
+    };
+    // (FULL: lane offset in the VGPR operand, row term in the SGPR operand; !FULL: both per lane)
+    auto ldv = [&](buf_rsrc rs, unsigned lane_off, unsigned rt) {
+        return FULL ? buf_load(rs, lane_off, rt) : buf_load(rs, lane_off + rt, 0u);
+    };
+    auto stv = [&](buf_rsrc rs, unsigned lane_off, unsigned rt, float v) {
+        if (FULL) buf_store(rs, lane_off, rt, v);
+        else buf_store(rs, lane_off + rt, 0u, v);
+    };
+
+    // gfx950 retires vector loads and stores through ONE in-order counter (vmcnt): a load issued after a store
+    // cannot be waited for without also waiting for that store's write acknowledgement, which turns a plain
+    // load / combine / store loop into a chain of round trips.  So the loads of batch i+1 are issued BEFORE the
+    // stores of batch i (bias comes from a register, see above), and scheduling barriers keep the compiler from
+    // re-bunching the batches (which it otherwise does, spilling what the loads return).
+    constexpr int NEG = 16 / EB;     // load batches per 32-row tile
+    constexpr int NBAT = MT * NEG;   // batches of EB rows x NT columns
+    const bool has_loads = has_res || accum;
+    // the divisor (mean over the resblock kernels) only ever comes with the accumulate form
+    const bool do_div = (LOADS == 2 || LOADS == 3) && a.out_div != 1.0f;
+    const float div_d = a.out_div, div_rd = 1.0f / a.out_div;
+    const bool gelu = GELU && a.epi == EPI_GELU_NEW;
+    const bool want_stats = a.stat_part != nullptr;
+    float rv[2][EB][NT], yv[2][ACCUM ? EB : 1][NT];
+    auto load_batch = [&](int bi, float (&rvb)[EB][NT], float (&yvb)[ACCUM ? EB : 1][NT]) {
+        const int mt = bi / NEG, eg = bi % NEG;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        for (int e8 = 0; e8 < EB; ++e8) {
+            const int rowu = row_of(mt, eg * EB + e8);
+            const unsigned rt = row_term(rowu, rrs), yt = row_term(rowu, yrs);
 #pragma unroll
-            for (int eg = 0; eg < 16 / EB; ++eg) {
-                float rv[EB][NT], yv[ACCUM ? EB : 1][NT], bv[EB];
-                long yo[EB];
-                bool rok[EB];
-#pragma unroll
-                for (int e8 = 0; e8 < EB; ++e8) {
-                    const int e = eg * EB + e8;
-                    const int row = row0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    rok[e8] = row < a.Cout;
-                    const int rowc = row < rmax ? row : rmax;
-                    yo[e8] = (long)rowc * yrs;
-                    bv[e8] = has_bias ? a.bias[rowc] : 0.f;
-                    const long ro = (long)rowc * a.r_ld;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        rv[e8][nt] = has_res ? a.resid[ro + rcol[nt]] : 0.f;
-                        if (ACCUM) yv[e8][nt] = a.y[yo[e8] + ycol[nt]];
-                    }
-                }
-                float rs[EB], rq[EB];
-#pragma unroll
-                for (int e8 = 0; e8 < EB; ++e8) {
-                    rs[e8] = 0.f;
-                    rq[e8] = 0.f;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        float v = acc[mt][nt][eg * EB + e8] * acc_scale + bv[e8];
-                        if (has_res) v += rv[e8][nt];
-                        if (ACCUM) v += yv[e8][nt];
-                        v *= a.out_mul;
-                        if (do_div) v = v / a.out_div;
-                        if (gelu) v = gelu_new_f(v);
-                        if (rok[e8] && cok[nt]) a.y[yo[e8] + ycol[nt]] = v;
-                        const float vm = cok[nt] ? v : 0.f;
-                        rs[e8] += vm;
-                        rq[e8] += vm * vm;
-                    }
-                }
-                if (a.stat_part) {
-                    // fused InstanceNorm statistics of what was just stored: reduce each row's partial over the
-                    // 32 lanes of this half-wave (lanes = columns), one (sum, sumsq) per row and column slot
-#pragma unroll
-                    for (int e8 = 0; e8 < EB; ++e8) {
-                        const float sv = half_wave_sum(rs[e8]), qv = half_wave_sum(rq[e8]);
-                        if (r == 0 && rok[e8]) {
-                            const int e = eg * EB + e8;
-                            const int row = row0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                            a.stat_part[((long)b * a.Cout + row) * a.stat_tiles + stat_slot] = make_float2(sv, qv);
-                        }
-                    }
+            for (int nt = 0; nt < NT; ++nt) {
+                if (LOADS == 3) {
+                    rvb[e8][nt] = has_res ? ldv(rbuf, roff[nt], rt) : 0.f;
+                    yvb[e8][nt] = accum ? ldv(ybuf, yoff[nt], yt) : 0.f;
+                } else {
+                    rvb[e8][nt] = ldv(rbuf, roff[nt], rt);
+                    if (ACCUM) yvb[e8][nt] = ldv(ybuf, yoff[nt], yt);
                 }
             }
         }
+    };
+    if (LOADS != 0 && has_loads) load_batch(0, rv[0], yv[0]);
+#pragma unroll
+    for (int bi = 0; bi < NBAT; ++bi) {
+        const int mt = bi / NEG, eg = bi % NEG;
+        if (LOADS != 0 && bi + 1 < NBAT && has_loads) load_batch(bi + 1, rv[(bi + 1) & 1], yv[(bi + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e8 = 0; e8 < EB; ++e8) {
+            const int e = eg * EB + e8;
+            const int rowu = row_of(mt, e);
+            const bool rok = FULL || rowu + 4 * h <= rmax;
+            const unsigned yt = row_term(rowu, yrs);  // (clamped rows are exactly the masked ones)
+            // this lane's row is tile row c (lower half-wave) or c + 4 (upper), c a compile-time constant
+            const int c = mt * 32 + (e & 3) + 8 * (e >> 2);
+            const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bias_lane), c));
+            const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bias_lane), c + 4));
+            const float bvv = h ? b1 : b0;
+            float rs = 0.f, rq = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v = acc[mt][nt][e] * acc_scale + bvv;
+                if (LOADS == 3) {
+                    if (has_loads) v += rv[bi & 1][e8][nt] + yv[bi & 1][e8][nt];
+                } else {
+                    if (LOADS >= 1) v += rv[bi & 1][e8][nt];
+                    if (LOADS == 2) v += yv[bi & 1][e8][nt];
+                }
+                v *= a.out_mul;
+                if (LOADS == 2) v = div_const(v, div_d, div_rd);  // (exact no-op for a divisor of 1)
+                if (LOADS == 3 && do_div) v = div_const(v, div_d, div_rd);
+                if (gelu) v = gelu_new_f(v);
+                if (FULL || (rok && cok[nt])) stv(ybuf, yoff[nt], yt, v);
+                const float vm = (FULL || cok[nt]) ? v : 0.f;
+                rs += vm;
+                rq += vm * vm;
+            }
+            if (want_stats) {
+                // fused InstanceNorm statistics of what was just stored: reduce the row's partial over the 32 lanes
+                // of this half-wave (lanes = columns), one (sum, sumsq) per row and column slot
+                const float sv = half_wave_sum(rs), qv = half_wave_sum(rq);
+                if (r == 0 && rok)
+                    a.stat_part[((long)b * a.Cout + rowu + 4 * h) * a.stat_tiles + stat_slot] = make_float2(sv, qv);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// EB = rows per load batch of the read-modify-write path (8 or 16)
-template <int MT, int NT, int EB = 8>
+// EB = rows per load batch of the read-modify-write path
+template <int MT, int NT, int EB, bool GELU>
 __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)[MT][NT], float acc_scale, int b,
                                                 int row0, int col0, int r, int h, int ncols, int Lout, int stat_slot) {
     if (a.store == ST_NORMAL || a.store == ST_TMAJOR) {
-        if (a.accum != 0 && a.store == ST_NORMAL)
-            conv_store_rmw<MT, NT, EB, true>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot);
-        else
-            conv_store_rmw<MT, NT, EB, false>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot);
+        const bool full = row0 + MT * 32 <= a.Cout && col0 + NT * 32 <= ncols;  // wave-uniform
+        const bool res = a.resid != nullptr && a.store == ST_NORMAL;
+        const bool accum = a.accum != 0 && a.store == ST_NORMAL;
+        if (!full)
+            conv_store_rmw<MT, NT, EB, 3, false, GELU>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot);
+        else if (res && accum)
+            conv_store_rmw<MT, NT, EB, 2, true, GELU>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot);
+        else if (res)
+            conv_store_rmw<MT, NT, EB, 1, true, GELU>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot);
+        else if (!accum)
+            conv_store_rmw<MT, NT, EB, 0, true, GELU>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot);
+        else  // accumulate without a residual: not a form the graph has; the edge path handles any combination
+            conv_store_rmw<MT, NT, EB, 3, false, GELU>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot);
         return;
     }
     // ST_UPSCATTER: polyphase transposed conv, GEMM row (p, co), column q -> out[co][s*q + p - pad]

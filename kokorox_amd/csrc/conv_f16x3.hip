@@ -25,7 +25,7 @@ using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using half2v = __attribute__((ext_vector_type(2))) _Float16;
 
 #ifndef KX_EPI_ROWS
-#define KX_EPI_ROWS 8
+#define KX_EPI_ROWS 4
 #endif
 constexpr int EPI_ROWS = KX_EPI_ROWS;  // rows per epilogue load batch
 constexpr int CK16 = 16;  // input channels per K-chunk
@@ -217,14 +217,24 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
             unsigned* dst_hi = Xs32 + ((vt * 4 + 0 * 2 + g) * XWp) * 4 + jw;
             unsigned* dst_lo = Xs32 + ((vt * 4 + 1 * 2 + g) * XWp) * 4 + jw;
             auto emit = [&](int u, float xA, float xB, bool pok) {
-                float yA = in_act<ACT>((xA - mA) * sA + hA, a.slope, aA, iA);
-                float yB = in_act<ACT>((xB - mB) * sB + hB, a.slope, aB, iB);
+                float yA, yB;
+                if (a.dbg & 32) {  // ablation: no activation arithmetic
+                    yA = (xA - mA) * sA + hA;
+                    yB = (xB - mB) * sB + hB;
+                } else {
+                    yA = in_act<ACT>((xA - mA) * sA + hA, a.slope, aA, iA);
+                    yB = in_act<ACT>((xB - mB) * sB + hB, a.slope, aB, iB);
+                }
                 yA = (pok && okA) ? yA : 0.f;  // zero padding comes after the activation
                 yB = (pok && okB) ? yB : 0.f;
                 unsigned hp, lp;
                 split_pair(yA, yB, hp, lp);
-                dst_hi[u * 4] = hp;
-                dst_lo[u * 4] = lp;
+                if (a.dbg & 64) {  // ablation: no LDS writes (one lane keeps the values alive)
+                    if (hp == 0x12345678u && lp == 0x9abcdef0u) dst_hi[0] = hp;
+                } else {
+                    dst_hi[u * 4] = hp;
+                    dst_lo[u * 4] = lp;
+                }
             };
             if (PF && from_raw) {
 #pragma unroll
@@ -336,7 +346,7 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
     if (a.stamps) st2 = __builtin_amdgcn_s_memrealtime();
     // ---- epilogue (conv_epilogue.h); accumulators carry the 2^ws weight scale -----------------------
     if (a.dbg & 8) return;
-    conv_store_tile<MT, NT, EPI_ROWS>(a, acc, a.w_unscale, b, ct * BM + wm * (MT * 32), t0 + wn * (NT * 32), r, h, ncols, Lout,
+    conv_store_tile<MT, NT, EPI_ROWS, (VT > 1)>(a, acc, a.w_unscale, b, ct * BM + wm * (MT * 32), t0 + wn * (NT * 32), r, h, ncols, Lout,
                             blockIdx.x * WN + wn);
     if (a.stamps && tid == 0) {  // stamps leave through a buffer of their own that nothing else reads
         const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -401,13 +411,8 @@ static void launch_inst16_tk(const ConvArgs& a, int B, int max_cols, hipStream_t
 
 template <int BM, int BN, int WM, int WN>
 static void launch_inst16(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
-    static const int tk = env_int("KX_TK", 3);
-    if (tk == 1)
-        launch_inst16_tk<BM, BN, WM, WN, 1>(a, B, max_cols, s);
-    else if (tk == 2)
-        launch_inst16_tk<BM, BN, WM, WN, 2>(a, B, max_cols, s);
-    else
-        launch_inst16_tk<BM, BN, WM, WN, 3>(a, B, max_cols, s);
+    // (weight pieces of 1 and 2 taps were measured too: no faster than 3 anywhere, so only TK = 3 is built)
+    launch_inst16_tk<BM, BN, WM, WN, 3>(a, B, max_cols, s);
 }
 
 int conv16_pick_bn(int BM, int max_cols) {
@@ -418,17 +423,22 @@ int conv16_pick_bn(int BM, int max_cols) {
 
 void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStream_t s) {
     KX_REQUIRE(a.n_chunks16 == (a.Cin + CK16 - 1) / CK16 && a.w16 != nullptr, "conv1d f16x3: weights not packed");
+    KX_REQUIRE(BM == 128 || a.epi != EPI_GELU_NEW, "conv1d f16x3: gelu epilogue needs the 128-row tile");
     if (max_cols <= 0) return;
     if (BM == 128) {
         // (an 8-wave x 128-register form of the 128x256 tile was tried: it spills and is 6 % slower)
         // (also tried: a 128x192 tile for 3 workgroups per CU: the 168-register cap spills in the main loop, 1.7x slower)
-        static const int vt_env = env_int("KX_VT", 1);
-        if (vt_env && a.K == 1 && a.stride == 1 && !a.stat_part && !a.in_up2 && a.n_chunks16 >= 3 && a.act != ACT_SNAKE) {
+        // k = 1 GEMMs (ALBERT, projections, LSTM input products) take the virtual-tap form; it is also the one
+        // kernel whose epilogue carries gelu_new
+        if (a.K == 1 && a.stride == 1 && !a.stat_part && !a.in_up2 && a.n_chunks16 >= 3 && a.act != ACT_SNAKE) {
             if (a.act == ACT_LEAKY)
                 launch_inst16_pf<128, 128, 2, 2, ACT_LEAKY, 3, true, 3>(a, B, max_cols, s);
             else
                 launch_inst16_pf<128, 128, 2, 2, ACT_NONE, 3, true, 3>(a, B, max_cols, s);
-        } else if (conv16_pick_bn(BM, max_cols) == 128)
+            return;
+        }
+        KX_REQUIRE(a.epi != EPI_GELU_NEW, "conv1d f16x3: gelu epilogue exists only for k=1 GEMMs with >= 48 input channels");
+        if (conv16_pick_bn(BM, max_cols) == 128)
             launch_inst16<128, 128, 2, 2>(a, B, max_cols, s);
         else
             launch_inst16<128, 256, 2, 2>(a, B, max_cols, s);

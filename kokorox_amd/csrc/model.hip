@@ -9,7 +9,9 @@
 namespace kx {
 
 static constexpr float RSQRT2 = 0.70710678118654752f;
-static inline int up4(int x) { return (x + 3) & ~3; }
+// row strides are multiples of 32 floats: every 32-column half-wave store of the conv epilogue is one whole
+// 128-byte line (arenas are 256-byte aligned)
+static inline int up4(int x) { return (x + 31) & ~31; }
 
 Model::Model(int dev) : device(dev) {
     if (const char* e = getenv("KOKOROX_CONV")) conv_mode = (strcmp(e, "f32") == 0) ? CONV_F32 : CONV_F16X3;
