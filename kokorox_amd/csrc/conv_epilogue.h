@@ -125,7 +125,9 @@ __device__ __forceinline__ void conv_store_rmw(const ConvArgs& a, f32x16 (&acc)[
     const float div_d = a.out_div, div_rd = 1.0f / a.out_div;
     const bool gelu = GELU && a.epi == EPI_GELU_NEW;
     const bool want_stats = a.stat_part != nullptr;
-    float rv[2][EB][NT], yv[2][ACCUM ? EB : 1][NT];
+    constexpr int DEPTH = ACCUM ? 1 : 2;  // load batches in flight ahead of the one being stored
+    constexpr int NBUF = DEPTH + 1;
+    float rv[NBUF][EB][NT], yv[NBUF][ACCUM ? EB : 1][NT];
     auto load_batch = [&](int bi, float (&rvb)[EB][NT], float (&yvb)[ACCUM ? EB : 1][NT]) {
         const int mt = bi / NEG, eg = bi % NEG;
 #pragma unroll
@@ -144,11 +146,15 @@ __device__ __forceinline__ void conv_store_rmw(const ConvArgs& a, f32x16 (&acc)[
             }
         }
     };
-    if (LOADS != 0 && has_loads) load_batch(0, rv[0], yv[0]);
+    if (LOADS != 0 && has_loads) {
+#pragma unroll
+        for (int d = 0; d < DEPTH && d < NBAT; ++d) load_batch(d, rv[d], yv[d]);
+    }
 #pragma unroll
     for (int bi = 0; bi < NBAT; ++bi) {
         const int mt = bi / NEG, eg = bi % NEG;
-        if (LOADS != 0 && bi + 1 < NBAT && has_loads) load_batch(bi + 1, rv[(bi + 1) & 1], yv[(bi + 1) & 1]);
+        if (LOADS != 0 && bi + DEPTH < NBAT && has_loads)
+            load_batch(bi + DEPTH, rv[(bi + DEPTH) % NBUF], yv[(bi + DEPTH) % NBUF]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e8 = 0; e8 < EB; ++e8) {
@@ -166,10 +172,10 @@ __device__ __forceinline__ void conv_store_rmw(const ConvArgs& a, f32x16 (&acc)[
             for (int nt = 0; nt < NT; ++nt) {
                 float v = acc[mt][nt][e] * acc_scale + bvv;
                 if (LOADS == 3) {
-                    if (has_loads) v += rv[bi & 1][e8][nt] + yv[bi & 1][e8][nt];
+                    if (has_loads) v += rv[bi % NBUF][e8][nt] + yv[bi % NBUF][e8][nt];
                 } else {
-                    if (LOADS >= 1) v += rv[bi & 1][e8][nt];
-                    if (LOADS == 2) v += yv[bi & 1][e8][nt];
+                    if (LOADS >= 1) v += rv[bi % NBUF][e8][nt];
+                    if (LOADS == 2) v += yv[bi % NBUF][e8][nt];
                 }
                 v *= a.out_mul;
                 if (LOADS == 2) v = div_const(v, div_d, div_rd);  // (exact no-op for a divisor of 1)

@@ -49,14 +49,14 @@ __device__ __forceinline__ float sin_sq(float t) {
 }
 
 // f32 -> (hi, lo) halves, two values packed per dword: hi = f16(v), lo = f16(v - hi)
+using float2v = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi_pk, unsigned& lo_pk) {
-    v0 = __builtin_fminf(__builtin_fmaxf(v0, -65504.f), 65504.f);
-    v1 = __builtin_fminf(__builtin_fmaxf(v1, -65504.f), 65504.f);
-    half2v h2, l2;
-    h2[0] = (_Float16)v0;
-    h2[1] = (_Float16)v1;
-    l2[0] = (_Float16)(v0 - (float)h2[0]);
-    l2[1] = (_Float16)(v1 - (float)h2[1]);
+    float2v v;
+    v[0] = __builtin_amdgcn_fmed3f(v0, -65504.f, 65504.f);
+    v[1] = __builtin_amdgcn_fmed3f(v1, -65504.f, 65504.f);
+    const half2v h2 = __builtin_convertvector(v, half2v);          // one v_cvt_pk_f16_f32
+    const float2v d = v - __builtin_convertvector(h2, float2v);
+    const half2v l2 = __builtin_convertvector(d, half2v);
     hi_pk = __builtin_bit_cast(unsigned, h2);
     lo_pk = __builtin_bit_cast(unsigned, l2);
 }
@@ -100,9 +100,12 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
     const int ncols = (a.store == ST_UPSCATTER) ? (Lin + 1) : Lout;
     if (t0 >= ncols) return;
 
-    const int K = a.K, dil = a.dil, stride = a.stride;
+    // The prefetching build (PF) is the stride-1 form with a fixed window pitch: every B-fragment address is then
+    // one per-lane base plus compile-time offsets (ds_read_b128 immediates) instead of a register each.
+    constexpr int XWP_FIXED = (VT > 1) ? 128 : BN + 128;
+    const int K = a.K, dil = a.dil, stride = PF ? 1 : a.stride;
     const int XW = (BN - 1) * stride + (K - 1) * dil + 1;
-    const int XWp = (XW + 3) & ~3;
+    const int XWp = PF ? XWP_FIXED : ((XW + 3) & ~3);
     constexpr int tap_units = 4 * BM;  // uint4 per tap: [hi|lo][h][BM]
     constexpr int piece_units = TK * tap_units;
     // LDS carve (16-B units): two weight-piece buffers, then Xs [hi|lo][octet][XWp]
@@ -143,139 +146,151 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
         for (int sgm = wave; sgm < nseg; sgm += NWV) glds16(src + sgm * 64 + lane, dst + sgm * 64);
     };
 
-    // ---- input chunk staging.  Wave w takes channel pairs w and w+4 of the chunk's 8 pairs; per-channel
-    // AdaIN / snake parameters are wave-uniform, lanes run along time (coalesced), and each lane writes one
-    // packed hi pair and one packed lo pair into the [time][8 ch] image.  With PF the raw values of the NEXT
-    // chunk are loaded into registers before the MFMA loop of the current one (their latency hides behind
-    // the matrix work) and are transformed + written after it.
-    constexpr int NI = (VT > 1) ? 2 : 5;  // PF needs XW <= 64 * NI (the launcher checks)
-    constexpr int NH = 8 / NWV;            // channel pairs staged per wave
-    float raw[VT][NH][NI][2];
-    // per-lane element offsets of this lane's NI window columns (they do not depend on the chunk)
-    int xoff[NI];
+    // ---- input chunk staging.  Wave w owns one channel octet of the 16-channel chunk (g = w & 1) and every
+    // other 64-column block of the window (blocks (w >> 1), (w >> 1) + 2, ...): lanes run along time (coalesced
+    // global loads), each lane gathers its column's 8 channels, applies AdaIN affine + activation, splits into
+    // f16 hi / lo and writes two whole 16-byte slots of the [time][8 ch] images (conflict-free ds_write_b128).
+    // The per-channel parameters travel in one register: lane c (mod 8) holds (mean, scale, shift, alpha) of
+    // channel c, handed out with v_readlane when the chunk is transformed.  With PF both the raw values and the
+    // parameters of the NEXT chunk are loaded before the MFMA loop of the current one (their latency hides
+    // behind the matrix work) and are transformed + written after it.
+    static_assert(NWV == 4, "the staging split assumes 4 waves");
+    constexpr int NJ = PF ? XWP_FIXED / 128 : 1;  // column blocks per wave: the PF window pitch is 128 * NJ columns
+    const int g = wave & 1, jb = wave >> 1;
+    float raw[VT][NJ][8];
+    float praw[VT][4];
+    // per-lane element offsets of this lane's NJ window columns (they do not depend on the chunk)
+    int xoff[NJ];
     unsigned okmask = 0;
     if (PF) {
 #pragma unroll
-        for (int it = 0; it < NI; ++it) {
-            const int p = p0 + lane + 64 * it;
+        for (int j = 0; j < NJ; ++j) {
+            const int p = p0 + lane + 64 * (jb + 2 * j);
             if (merged) {
                 const int pc = p < Lin ? p : Lin - 1;
                 const int bb = pc / a.merge_T, tt = pc - bb * a.merge_T;
                 const bool ok = p < Lin && tt < a.in_len.lens[bb];
-                okmask |= ok ? (1u << it) : 0u;
-                xoff[it] = (int)((long)bb * a.x_bs + tt);
+                okmask |= ok ? (1u << j) : 0u;
+                xoff[j] = (int)((long)bb * a.x_bs + tt);
             } else {
-                okmask |= (p >= 0 && p < Lin) ? (1u << it) : 0u;
+                okmask |= (p >= 0 && p < Lin) ? (1u << j) : 0u;
                 int pi = up2 ? (p >> 1) : p;
                 pi = pi < 0 ? 0 : (pi >= Lsrc ? Lsrc - 1 : pi);
-                xoff[it] = pi;
+                xoff[j] = pi;
             }
         }
     }
     const float* xbase = merged ? a.x : xb;
+    const int cmax_in = a.Cin - 1;
+    auto load_params = [&](int ch, float (&pv)[4]) {
+        const int c = ch * CK16 + g * 8 + (lane & 7);
+        const int cc = c < cmax_in ? c : cmax_in;
+        pv[0] = has_norm ? a.nmean[(long)b * a.n_bs + cc] : 0.f;
+        pv[1] = has_norm ? a.nscale[(long)b * a.n_bs + cc] : 1.f;
+        pv[2] = has_norm ? a.nshift[(long)b * a.n_bs + cc] : 0.f;
+        const float al = (ACT == ACT_SNAKE) ? a.alpha[cc] : 1.f;
+        pv[3] = (lane & 8) ? 1.0f / al : al;  // lanes 8..15: the reciprocals
+    };
     auto load_raw = [&](int sc) {
 #pragma unroll
         for (int vt = 0; vt < VT; ++vt) {
             const int ch = sc * VT + vt;  // 16-channel chunk staged as virtual tap vt
+            load_params(ch, praw[vt]);
 #pragma unroll
-            for (int half = 0; half < NH; ++half) {
-                const int cA = ch * CK16 + 2 * (wave + NWV * half), cB = cA + 1;
-                const float* rowA = xbase + (long)(cA < a.Cin ? cA : 0) * a.x_ld;
-                const float* rowB = xbase + (long)(cB < a.Cin ? cB : 0) * a.x_ld;
+            for (int c = 0; c < 8; ++c) {
+                const int ci = ch * CK16 + g * 8 + c;
+                const float* row = xbase + (long)(ci < cmax_in ? ci : cmax_in) * a.x_ld;
 #pragma unroll
-                for (int it = 0; it < NI; ++it) {
-                    raw[vt][half][it][0] = rowA[xoff[it]];
-                    raw[vt][half][it][1] = rowB[xoff[it]];
-                }
+                for (int j = 0; j < NJ; ++j) raw[vt][j][c] = row[xoff[j]];
             }
         }
+    };
+    // per-channel parameters of one octet, unpacked into scalar registers once per chunk
+    struct Oct { float m[8], s[8], h[8], al[8], ial[8]; };
+    auto unpack_params = [&](const float (&pv)[4], Oct& o) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            o.m[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv[0]), c));
+            o.s[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv[1]), c));
+            o.h[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv[2]), c));
+            o.al[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv[3]), c));
+            o.ial[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv[3]), c + 8));
+        }
+    };
+    // transform one column's 8 channels and write its two 16-byte slots
+    auto emit8 = [&](int vt, int ch, int u, const float (&x8)[8], const Oct& o, bool pok) {
+        unsigned hp[4], lp[4];
+        const float keep = pok ? 1.f : 0.f;
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2) {
+            float y2[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c = 2 * c2 + q;
+                const float y = in_act<ACT>((x8[c] - o.m[c]) * o.s[c] + o.h[c], a.slope, o.al[c], o.ial[c]);
+                // zero padding comes after the activation (a multiply, so that the activation stays branch-free;
+                // masked positions hold clamped-address tensor values, i.e. finite numbers)
+                y2[q] = y * ((ch * CK16 + g * 8 + c <= cmax_in) ? keep : 0.f);
+            }
+            split_pair(y2[0], y2[1], hp[c2], lp[c2]);
+        }
+        Xs[(vt * 4 + 0 * 2 + g) * XWp + u] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+        Xs[(vt * 4 + 1 * 2 + g) * XWp + u] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
     };
     auto stage_chunk = [&](int sc, bool from_raw) {
 #pragma unroll
-      for (int vt = 0; vt < VT; ++vt) {
-        const int ch = sc * VT + vt;
-#pragma unroll
-        for (int half = 0; half < NH; ++half) {
-            const int pr = wave + NWV * half;  // pair index 0..7 inside the 16-channel chunk
-            const int cA = ch * CK16 + 2 * pr, cB = cA + 1;
-            const bool okA = cA < a.Cin, okB = cB < a.Cin;
-            const int cAc = okA ? cA : 0, cBc = okB ? cB : 0;  // clamped: loads stay in bounds, result masked
-            float mA = 0.f, sA = 1.f, hA = 0.f, aA = 1.f, iA = 1.f, mB = 0.f, sB = 1.f, hB = 0.f, aB = 1.f, iB = 1.f;
-            if (has_norm) {
-                const long nA = (long)b * a.n_bs + cAc, nB = (long)b * a.n_bs + cBc;
-                mA = a.nmean[nA]; sA = a.nscale[nA]; hA = a.nshift[nA];
-                mB = a.nmean[nB]; sB = a.nscale[nB]; hB = a.nshift[nB];
-            }
-            if (ACT == ACT_SNAKE) {
-                aA = a.alpha[cAc]; iA = 1.0f / aA;
-                aB = a.alpha[cBc]; iB = 1.0f / aB;
-            }
-            const float* rowA = xbase + (long)cAc * a.x_ld;
-            const float* rowB = xbase + (long)cBc * a.x_ld;
-            // dword index of (hi image, octet g, column 0, channel slot j): ((0*2+g)*XWp)*4 + j/2
-            const int g = pr >> 2, jw = pr & 3;
-            unsigned* dst_hi = Xs32 + ((vt * 4 + 0 * 2 + g) * XWp) * 4 + jw;
-            unsigned* dst_lo = Xs32 + ((vt * 4 + 1 * 2 + g) * XWp) * 4 + jw;
-            auto emit = [&](int u, float xA, float xB, bool pok) {
-                float yA, yB;
-                if (a.dbg & 32) {  // ablation: no activation arithmetic
-                    yA = (xA - mA) * sA + hA;
-                    yB = (xB - mB) * sB + hB;
-                } else {
-                    yA = in_act<ACT>((xA - mA) * sA + hA, a.slope, aA, iA);
-                    yB = in_act<ACT>((xB - mB) * sB + hB, a.slope, aB, iB);
-                }
-                yA = (pok && okA) ? yA : 0.f;  // zero padding comes after the activation
-                yB = (pok && okB) ? yB : 0.f;
-                unsigned hp, lp;
-                split_pair(yA, yB, hp, lp);
-                if (a.dbg & 64) {  // ablation: no LDS writes (one lane keeps the values alive)
-                    if (hp == 0x12345678u && lp == 0x9abcdef0u) dst_hi[0] = hp;
-                } else {
-                    dst_hi[u * 4] = hp;
-                    dst_lo[u * 4] = lp;
-                }
-            };
+        for (int vt = 0; vt < VT; ++vt) {
+            const int ch = sc * VT + vt;
+            Oct o;
             if (PF && from_raw) {
+                unpack_params(praw[vt], o);
+                // (columns past the window but inside the fixed pitch get clamped-address garbage that no
+                // fragment read ever touches)
 #pragma unroll
-                for (int it = 0; it < NI; ++it) {
-                    const int u = lane + 64 * it;
-                    if (u < XW) emit(u, raw[vt][half][it][0], raw[vt][half][it][1], ((okmask >> it) & 1u) != 0u);
-                }
+                for (int j = 0; j < NJ; ++j)
+                    emit8(vt, ch, lane + 64 * (jb + 2 * j), raw[vt][j], o, ((okmask >> j) & 1u) != 0u);
             } else {
+                float pv[4];
+                load_params(ch, pv);
+                unpack_params(pv, o);
                 if (PF) {  // first chunk of the prefetching build: same hoisted offsets, loads issued here
 #pragma unroll
-                    for (int it = 0; it < NI; ++it) {
-                        const int u = lane + 64 * it;
-                        if (u < XW) emit(u, rowA[xoff[it]], rowB[xoff[it]], ((okmask >> it) & 1u) != 0u);
+                    for (int j = 0; j < NJ; ++j) {
+                        float x8[8];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const int ci = ch * CK16 + g * 8 + c;
+                            x8[c] = xbase[(long)(ci < cmax_in ? ci : cmax_in) * a.x_ld + xoff[j]];
+                        }
+                        emit8(vt, ch, lane + 64 * (jb + 2 * j), x8, o, ((okmask >> j) & 1u) != 0u);
                     }
                 } else {
-                    for (int u = lane; u < XW; u += 64) {
+                    for (int u = lane + 64 * jb; u < XW; u += 128) {
                         const int p = p0 + u;
                         int pi = up2 ? (p >> 1) : p;
                         pi = pi < 0 ? 0 : (pi >= Lsrc ? Lsrc - 1 : pi);
-                        emit(u, rowA[pi], rowB[pi], p >= 0 && p < Lin);
+                        float x8[8];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const int ci = ch * CK16 + g * 8 + c;
+                            x8[c] = xbase[(long)(ci < cmax_in ? ci : cmax_in) * a.x_ld + pi];
+                        }
+                        emit8(vt, ch, u, x8, o, p >= 0 && p < Lin);
                     }
                 }
             }
         }
-      }
     };
 
-    // Co-resident workgroups of one CU start together and would stay in lockstep (staging with staging,
-    // MFMA with MFMA, epilogue with epilogue).  Delay the second first-round workgroup of every CU once, so
-    // that one block's memory/VALU phases run beside the other's matrix phase; later blocks inherit the offset.
-    if (a.stagger_ticks > 0) {
-        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const bool delayed = (a.dbg & 16) ? (((lin >> 3) & 1u) != 0u) : (lin >= 256u);
-        if (lin < 512u && delayed) {
-            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-            while (__builtin_amdgcn_s_memrealtime() - t_start < (unsigned long long)a.stagger_ticks)
-                __builtin_amdgcn_s_sleep(32);
-        }
+    // (Tried and measured without effect on throughput: a one-off start stagger of the co-resident workgroups, and
+    // distinct static s_setprio classes per CU handed out through a flag word.  The favoured workgroup's main loop
+    // got 12 % shorter, the other one's as much longer.)
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, acc_stage = 0, acc_bar = 0, acc_pbar = 0;
+    unsigned long long cyc0 = 0;
+    if (a.stamps) {
+        st0 = __builtin_amdgcn_s_memrealtime();
+        cyc0 = __builtin_readcyclecounter();
     }
-    unsigned long long st0 = 0, st1 = 0, st2 = 0, acc_stage = 0, acc_bar = 0;
-    if (a.stamps) st0 = __builtin_amdgcn_s_memrealtime();
     issue_piece(0, 0, 0);
     if (!(a.dbg & 1)) stage_chunk(0, false);
     __syncthreads();  // Xs complete; the in-flight weight piece has landed (the barrier drains vmcnt)
@@ -294,40 +309,62 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
             int taps = (K - tp) < TK ? (K - tp) : TK;
             if (VT > 1) taps = (n_chunks16 - ch * VT) < VT ? (n_chunks16 - ch * VT) : VT;
             const uint4* Wp = Wbuf + cur * piece_units;
-            for (int tt = 0; tt < ((a.dbg & 4) ? 0 : taps); ++tt) {
-                const int tap = tp + tt;
-                half8 ah[MT], al_[MT], bh[NT], bl[NT];
-                const uint4* wt = Wp + tt * tap_units + h * BM + wm * (MT * 32) + r;
+            // Fragment reads are software-pipelined inside the piece so that only the first read of a piece waits
+            // on LDS with an idle matrix pipe.  P = {a_lo, b_hi} feeds the first 8 MFMAs of a tap, Q = {a_hi, b_lo}
+            // (+ b_hi again) the other 16: Q(t) is read under the P-phase of tap t, P(t+1) under its Q-phase.
+            const uint4* wl = Wp + h * BM + wm * (MT * 32) + r;
+            const uint4* xl = Xs + h * XWp + (wn * (NT * 32) + r) * stride;
+            auto load_P = [&](int tt, half8 (&al)[MT], half8 (&bh)[NT]) {
+                const uint4* wt = wl + tt * tap_units;
+                const uint4* xt = (VT > 1) ? xl + tt * 4 * XWp : xl + (tp + tt) * dil;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    ah[mt] = *reinterpret_cast<const half8*>(&wt[mt * 32]);
-                    al_[mt] = *reinterpret_cast<const half8*>(&wt[2 * BM + mt * 32]);
-                }
-                const uint4* xt = (VT > 1) ? Xs + (tt * 4 + h) * XWp + (wn * (NT * 32) + r) * stride
-                                           : Xs + h * XWp + (wn * (NT * 32) + r) * stride + tap * dil;
+                for (int mt = 0; mt < MT; ++mt) al[mt] = *reinterpret_cast<const half8*>(&wt[2 * BM + mt * 32]);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    bh[nt] = *reinterpret_cast<const half8*>(&xt[nt * 32 * stride]);
-                    bl[nt] = *reinterpret_cast<const half8*>(&xt[2 * XWp + nt * 32 * stride]);
-                }
+                for (int nt = 0; nt < NT; ++nt) bh[nt] = *reinterpret_cast<const half8*>(&xt[nt * 32 * stride]);
+            };
+            auto load_Q = [&](int tt, half8 (&ah)[MT], half8 (&bl)[NT]) {
+                const uint4* wt = wl + tt * tap_units;
+                const uint4* xt = (VT > 1) ? xl + tt * 4 * XWp : xl + (tp + tt) * dil;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt) ah[mt] = *reinterpret_cast<const half8*>(&wt[mt * 32]);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) bl[nt] = *reinterpret_cast<const half8*>(&xt[2 * XWp + nt * 32 * stride]);
+            };
+            if (!(a.dbg & 4)) {
+                half8 al_[2][MT], bh[2][NT], ah[MT], bl[NT];
+                load_P(0, al_[0], bh[0]);
+#pragma unroll
+                for (int tt = 0; tt < TK; ++tt) {
+                    if (tt < taps) {
+                        load_Q(tt, ah, bl);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_[tt & 1][mt], bh[tt & 1][nt], acc[mt][nt], 0, 0, 0);
+                        if (tt + 1 < TK && tt + 1 < taps) load_P(tt + 1, al_[(tt + 1) & 1], bh[(tt + 1) & 1]);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[tt & 1][nt], acc[mt][nt], 0, 0, 0);
+                            }
                     }
+                }
             }
             // Everyone must be done with Wbuf[cur] (and with Xs after the last piece).  After the last piece of a
             // chunk a raw barrier with lgkmcnt(0) only is enough: the transform of the next chunk follows, and the
             // weight piece that was just issued stays in flight across it (a __syncthreads() would drain vmcnt and
             // expose the copy latency right behind a short MFMA burst); the full barrier after the transform
             // retires it.  Between pieces of one chunk the next piece must have landed: full barrier.
+            unsigned long long tp0 = 0;
+            if (a.stamps) tp0 = __builtin_amdgcn_s_memrealtime();
             if (pc + 1 == n_pieces && more)
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else
                 __syncthreads();
+            if (a.stamps) acc_pbar += __builtin_amdgcn_s_memrealtime() - tp0;
             cur ^= 1;
         }
         if (more) {
@@ -355,9 +392,9 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
         __builtin_amdgcn_s_waitcnt(0);
         o[3] = __builtin_amdgcn_s_memrealtime();
         o[4] = __builtin_amdgcn_s_getreg(63492);  // HW_REG_HW_ID
-        o[5] = __builtin_amdgcn_s_getreg(63508);  // HW_REG_XCC_ID
+        o[5] = __builtin_readcyclecounter() - cyc0;  // shader-clock cycles of this workgroup (o[3] - o[0] is real time)
         o[6] = acc_stage;
-        o[7] = acc_bar;
+        o[7] = acc_bar | (acc_pbar << 32);
     }
 }
 
@@ -371,8 +408,11 @@ static void launch_inst16_pf(const ConvArgs& a, int B, int max_cols, hipStream_t
     static size_t lds_limit = 64 * 1024;  // raise the dynamic-LDS limit only as far as a launch needs
     auto kern = conv1d_f16x3_kernel<BM, BN, WM, WN, ACT, TK, PF, VT>;
     const int XW = (BN - 1) * a.stride + (a.K - 1) * a.dil + 1;
-    const int XWp = (XW + 3) & ~3;
-    const size_t lds = 16 * ((size_t)2 * TK * 4 * BM + (size_t)VT * 4 * XWp);
+    const int XWp = PF ? ((VT > 1) ? 128 : BN + 128) : ((XW + 3) & ~3);  // (as in the kernel)
+    KX_REQUIRE(!PF || (a.stride == 1 && XW <= XWp), "conv1d f16x3: the prefetching build needs stride 1 and a window <= BN + 128");
+    static const int lds_pad = env_int("KX_LDS_PAD", 0);  // diagnostic: extra LDS to force one workgroup per CU
+    size_t lds = 16 * ((size_t)2 * TK * 4 * BM + (size_t)VT * 4 * XWp);
+    if (lds + lds_pad <= 160 * 1024) lds += lds_pad;
     KX_REQUIRE(lds <= 160 * 1024, "conv1d f16x3: LDS tile too large for this k/stride");
     KX_REQUIRE(VT == 1 || (a.K == 1 && a.stride == 1 && XW <= 128), "conv1d f16x3: virtual taps need a k=1 GEMM");
     if (lds > lds_limit) {
@@ -393,7 +433,7 @@ template <int BM, int BN, int WM, int WN, int ACT, int TK>
 static void launch_inst16_act(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
     static const int pf_env = env_int("KX_PF", 1);
     const int XW = (BN - 1) * a.stride + (a.K - 1) * a.dil + 1;
-    if (pf_env && XW <= 320)
+    if (pf_env && a.stride == 1 && XW <= BN + 128)
         launch_inst16_pf<BM, BN, WM, WN, ACT, TK, true>(a, B, max_cols, s);
     else
         launch_inst16_pf<BM, BN, WM, WN, ACT, TK, false>(a, B, max_cols, s);

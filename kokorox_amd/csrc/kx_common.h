@@ -88,7 +88,6 @@ struct ConvArgs {
     int merge_B;
     float2* stat_part;  // optional [B][Cout][stat_tiles] partial (sum, sum of squares) of the stored values
     int stat_tiles;
-    int stagger_ticks;  // first-round stagger of co-resident workgroups, in 100 MHz ticks (0 = off)
     unsigned long long* stamps;  // diagnostic build only: per-workgroup {t0,t1,t2,t3,hw_id,xcc_id,0,0}
     int dbg;  // timing ablations (env KX_DBG): 1 skip input staging, 2 skip weight copies, 4 skip MFMA, 8 skip epilogue
 };

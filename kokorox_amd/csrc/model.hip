@@ -405,12 +405,6 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     }
     static const int dbg_env = getenv("KX_DBG") ? atoi(getenv("KX_DBG")) : 0;
     a.dbg = dbg_env;
-    {
-        // matrix-pipe time of one 128 x 256 workgroup tile in microseconds (3 MFMAs of 32 cycles per 32x32x16 block)
-        static const double stag_env = getenv("KX_STAGGER") ? atof(getenv("KX_STAGGER")) : 0.0;
-        const double mfma_cycles = 4.0 * 8.0 * ((w.Cin + 15) / 16) * w.K * 3.0 * 32.0 / 4.0;
-        a.stagger_ticks = (int)(stag_env * mfma_cycles / 2400.0 * 100.0);
-    }
     int max_cols = (o.store == ST_UPSCATTER) ? in.Lmax + 1 : out.Lmax;
     static const bool merge_env = !(getenv("KX_MERGE") && atoi(getenv("KX_MERGE")) == 0);
     if (merge_env && f16 && B_ > 1 && w.K == 1 && o.stride == 1 && o.pad == 0 && !o.in_up2 && !o.nmean &&
