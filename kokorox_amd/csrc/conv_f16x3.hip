@@ -31,21 +31,22 @@ constexpr int EPI_ROWS = KX_EPI_ROWS;  // rows per epilogue load batch
 constexpr int CK16 = 16;  // input channels per K-chunk
 constexpr int TK_MAX = 3;  // taps per weight piece in LDS (template parameter TK <= this)
 
-// sin^2(t) for moderate |t| (snake activations): Cody-Waite reduction to |r| <= pi/4 by multiples of
-// pi/2, even Taylor series of sin^2 on the reduced argument, complement on odd quadrants.
-// Absolute error ~1e-7 for |t| < 1e3 (tests/test_gpu_kernels.py checks the fused conv against f64).
+// sin^2(t) for moderate |t| (snake activations).  sin^2 has period pi and is even about every multiple of it, so
+// one Cody-Waite reduction to r = t - n pi, |r| <= pi/2, and one even polynomial do the whole job, with no quadrant
+// select: sin^2(r) = z P(z), z = r^2, P a degree-5 near-minimax fit on [0, (pi/2)^2] (approximation error 2.5e-8;
+// 1.6e-7 worst case as evaluated in f32, tools/probes/sin_accuracy.hip).  14 vector instructions with the
+// surrounding alpha multiply and the final fma, against 19 for the quarter-period form with its parity select.
 __device__ __forceinline__ float sin_sq(float t) {
-    const float n = rintf(t * 0.636619772367581343f);         // t / (pi/2)
-    float r = fmaf(n, -1.57079625129699707031f, t);            // pi/2 high part (exact in 17 bits)
-    r = fmaf(n, -7.54978941586159635335e-08f, r);              // pi/2 low part
-    const float r2 = r * r;
-    float p = fmaf(r2, -4.27561049e-06f, 1.41093474e-04f);     // -2/467775, 2/14175
-    p = fmaf(r2, p, -3.17460317e-03f);                         // -1/315
-    p = fmaf(r2, p, 4.44444444e-02f);                          // 2/45
-    p = fmaf(r2, p, -3.33333333e-01f);                         // -1/3
-    p = fmaf(r2, p, 1.0f);
-    const float s2 = r2 * p;
-    return (((int)n) & 1) ? 1.0f - s2 : s2;
+    const float n = rintf(t * 0.318309886183790672f);          // t / pi
+    float r = fmaf(n, -3.14159274101257324f, t);                // pi, high part (the f32 nearest pi)
+    r = fmaf(n, 8.74227765734758578e-08f, r);                   // minus the low part (pi - hi = -8.74e-8)
+    const float z = r * r;
+    float p = fmaf(z, -3.6197402550897095e-06f, 1.3928599946666651e-04f);
+    p = fmaf(z, p, -3.1722760759294033e-03f);
+    p = fmaf(z, p, 4.4443082064390182e-02f);
+    p = fmaf(z, p, -3.3333304524421692e-01f);
+    p = fmaf(z, p, 1.0f);
+    return z * p;
 }
 
 // f32 -> (hi, lo) halves, two values packed per dword: hi = f16(v), lo = f16(v - hi)

@@ -1,8 +1,4 @@
-set -e
-R=$GRAFT_REPO_ROOT
+./tools/probes/sin_accuracy.bin
 timeout -k 10 600 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r1b -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-utts 0 --free-run 0 > $R/gpurun_out/prof_r1b_bench.json 2> $R/gpurun_out/prof_r1b.log
-cd $R
-python tools/summarize_rocprof.py gpurun_out/prof_r1b gpurun_out/prof_r1b_bench.json gpurun_out/kernel_stats_new.txt
-head -32 gpurun_out/kernel_stats_new.txt | cut -c1-140
+timeout -k 10 200 python bench.py --steps 3 --warmup 1 --cpu-utts 0 --free-run 0 --detail gpurun_out/var_sin.txt 2>&1 | grep -E "timed"
+head -9 gpurun_out/var_sin.txt

@@ -1,21 +1,20 @@
 // Probe: absolute error of sin^2 evaluated three ways on gfx950, against f64.
-//   (a) Cody-Waite + polynomial (what conv_f16x3.hip uses), (b) 0.5 - 0.5 * v_cos_f32(t / pi turns), (c) v_sin_f32 squared
+//   (a) period-pi Cody-Waite + degree-5 polynomial (what conv_f16x3.hip uses), (b) 0.5 - 0.5 * v_cos_f32(t / pi turns), (c) v_sin_f32 squared
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
 #include <vector>
-__device__ float sin_sq_poly(float t) {
-    const float n = rintf(t * 0.636619772367581343f);
-    float r = fmaf(n, -1.57079625129699707031f, t);
-    r = fmaf(n, -7.54978941586159635335e-08f, r);
-    const float r2 = r * r;
-    float p = fmaf(r2, -4.27561049e-06f, 1.41093474e-04f);
-    p = fmaf(r2, p, -3.17460317e-03f);
-    p = fmaf(r2, p, 4.44444444e-02f);
-    p = fmaf(r2, p, -3.33333333e-01f);
-    p = fmaf(r2, p, 1.0f);
-    const float s2 = r2 * p;
-    return (((int)n) & 1) ? 1.0f - s2 : s2;
+__device__ float sin_sq_poly(float t) {  // the form used by conv_f16x3.hip
+    const float n = rintf(t * 0.318309886183790672f);
+    float r = fmaf(n, -3.14159274101257324f, t);
+    r = fmaf(n, 8.74227765734758578e-08f, r);
+    const float z = r * r;
+    float p = fmaf(z, -3.6197402550897095e-06f, 1.3928599946666651e-04f);
+    p = fmaf(z, p, -3.1722760759294033e-03f);
+    p = fmaf(z, p, 4.4443082064390182e-02f);
+    p = fmaf(z, p, -3.3333304524421692e-01f);
+    p = fmaf(z, p, 1.0f);
+    return z * p;
 }
 __global__ void k(const float* t, float* o, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
