@@ -219,6 +219,66 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)
         return;
     }
     // ST_UPSCATTER: polyphase transposed conv, GEMM row (p, co), column q -> out[co][s*q + p - pad]
+    const int rows_here = MT * 32;
+    const int q_lo = col0, q_hi = col0 + NT * 32 - 1;
+    // interior block: all rows valid, all columns valid, every phase of every column lands inside [0, Lout), and no
+    // row of the block wraps the (p, co) split more than once -> branch-free form with scalar row terms
+    const bool interior = row0 + rows_here <= a.Cout && q_hi < ncols && a.up_s * q_lo - a.up_pad >= 2 &&
+                          a.up_s * q_hi + (a.up_s - 1) - a.up_pad < Lout && a.up_cout >= rows_here;
+    if (interior) {
+        const buf_rsrc ybuf = make_buf(a.y + (long)b * a.y_bs);
+        const buf_rsrc rbuf = make_buf(a.resid ? a.resid + (long)b * a.r_bs : a.y);
+        const bool has_res = a.resid != nullptr;
+        const int brow = row0 + r + 32 * h;  // bias of the wave's rows, one per lane (row -> co below)
+        const int bp = brow / a.up_cout;
+        const float bias_lane = a.bias ? a.bias[brow - bp * a.up_cout] : 0.f;
+        unsigned qoff[NT];  // byte offset of column q inside an output row: 4 * s * q
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) qoff[nt] = 4u * (unsigned)(a.up_s * (col0 + nt * 32 + r));
+        const int p0 = row0 / a.up_cout, co0 = row0 - p0 * a.up_cout;  // (wave-uniform)
+        // rows come in pairs (c, c + 4) split over the half-waves; their uniform byte terms for y and resid
+        auto row_terms = [&](int d, unsigned& yt, unsigned& rt) {
+            int co = co0 + d, pp = p0;
+            if (co >= a.up_cout) { co -= a.up_cout; ++pp; }
+            const int t = pp - a.up_pad + a.up_off;
+            yt = 4u * (unsigned)(co * a.y_ld + t);
+            rt = 4u * (unsigned)(co * a.r_ld + t);
+        };
+        // residual loads of a whole 32-row tile are issued before its stores (see conv_store_rmw on vmcnt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int eg = 0; eg < 4; ++eg) {
+                float rv[4][NT];
+                unsigned yts[4];
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int e = eg * 4 + e4;
+                    const int c = mt * 32 + (e & 3) + 8 * (e >> 2);
+                    unsigned y0, r0, y1, r1;
+                    row_terms(c, y0, r0);
+                    row_terms(c + 4, y1, r1);
+                    yts[e4] = h ? y1 : y0;
+                    const unsigned rts = h ? r1 : r0;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) rv[e4][nt] = has_res ? buf_load(rbuf, qoff[nt] + rts, 0u) : 0.f;
+                }
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int e = eg * 4 + e4;
+                    const int c = mt * 32 + (e & 3) + 8 * (e >> 2);
+                    const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bias_lane), c));
+                    const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bias_lane), c + 4));
+                    const float bvv = h ? b1 : b0;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        buf_store(ybuf, qoff[nt] + yts[e4], 0u, acc[mt][nt][e] * acc_scale + bvv + rv[e4][nt]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return;
+    }
     float* yb = a.y + (long)b * a.y_bs;
     const float* rb = a.resid ? a.resid + (long)b * a.r_bs : nullptr;
 #pragma unroll
