@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a) {
     }
 
     // ---- epilogue (conv_epilogue.h) -------------------------------------------------------------
-    conv_store_tile<MT, NT, 8, (BM == 128 && BN == 128)>(a, acc, 1.0f, b, ct * BM + wm * (MT * 32), t0 + wn * (NT * 32), r, h, ncols, Lout,
+    conv_store_tile<MT, NT, 4, (BM == 128 && BN == 128)>(a, acc, 1.0f, b, ct * BM + wm * (MT * 32), t0 + wn * (NT * 32), r, h, ncols, Lout,
                             blockIdx.x * WN + wn);
 }
 

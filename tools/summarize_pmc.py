@@ -19,10 +19,13 @@ def load(pat):
     return agg
 
 
-def main(fetch_dir, write_dir, out, stats_known_bytes_per_step):
+def main(fetch_dir, write_dir, out, stats_known_bytes_per_step, family="conv1d_mfma_kernel<128, 128, 2, 2>", mode="f32"):
     f = load(fetch_dir + "/*/*_counter_collection.csv")
     w = load(write_dir + "/*/*_counter_collection.csv")
-    conv = [k for k in f if "conv1d_mfma_kernel<128, 128, 2, 2>" in k][0]
+    fam = [k for k in f if family in k]  # every instance of the BM=128 family counts as the dominant kernel
+    conv = family + (" (family, %d instances)" % len(fam) if len(fam) > 1 else "")
+    f[conv] = [sum(f[k][0] for k in fam), sum(f[k][1] for k in fam)]
+    w[conv] = [sum(w[k][0] for k in fam), sum(w[k][1] for k in fam)]
     st = [k for k in f if "in_stats_kernel" in k][0]
     calib = float(stats_known_bytes_per_step) / (f[st][1] * 1024)
     n = f[conv][0]
@@ -36,10 +39,10 @@ def main(fetch_dir, write_dir, out, stats_known_bytes_per_step):
         "write_bytes_per_launch": w[conv][1] / n * 1024,
     }
     res["traffic_bytes_per_launch"] = res["fetch_bytes_per_launch_corrected"] + res["write_bytes_per_launch"]
-    res["workload"] = {"batch": 64, "tokens": 130, "frames": 422}
+    res["workload"] = {"batch": 64, "tokens": 130, "frames": 422, "conv_mode": mode}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:7])
