@@ -1,5 +1,6 @@
-timeout -k 10 300 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu 2>&1 | tail -5 && \
-timeout -k 10 400 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 && \
-timeout -k 10 200 python bench.py --steps 3 --warmup 1 --cpu-utts 0 --free-run 0 --detail gpurun_out/var_dual.txt 2>&1 | grep -E "timed" && \
-head -12 gpurun_out/var_dual.txt && \
-KX_DUAL=0 timeout -k 10 200 python bench.py --steps 3 --warmup 1 --cpu-utts 0 --free-run 0 2>&1 | grep -E "timed"
+# A/B harness used for the kernel experiments recorded in DESIGN.md §5: run on the GPU box through gpurun, e.g.
+#   gpurun -- 'KX_DBG=4 bash tools/ablate.sh'      (KX_DBG bits: 1 no input staging, 2 no weight copies, 4 no MFMAs,
+#                                                   8 no epilogue; KX_LDS_PAD=30000 forces one workgroup per CU)
+# Prints the step time and the per-shape table of the conv launches of one step.
+timeout -k 10 300 python bench.py --steps 3 --warmup 1 --cpu-utts 0 --free-run 0 --detail gpurun_out/ablate_shapes.txt 2>&1 | grep -E "timed"
+head -14 gpurun_out/ablate_shapes.txt
