@@ -136,66 +136,7 @@ void launch_layernorm_ch(const float* x, float* y, long bs, int ld, int C, LenMa
 }
 
 // ---- ALBERT self-attention, 12 heads x 64, T <= 512 ---------------------------------------
-// qkv [B][2304][ld] = rows [Q | K | V]; one workgroup per (utterance, head), one wave per
-// query row: lanes span keys for QK^T + softmax (wave shuffles), then span the 64 head
-// dims for P.V.  ~0.1 % of the model's FLOPs.
-__global__ __launch_bounds__(256) void attention_kernel(const float* qkv, long bs, int ld, float* ctx, long cbs,
-                                                        int cld, const int* lens) {
-    __shared__ float ps[4][512];
-    __shared__ float qs[4][64];
-    const int b = blockIdx.x, hd = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int T = lens[b];
-    const float* Q = qkv + b * bs + (long)(hd * 64) * ld;
-    const float* Kp = Q + (long)768 * ld;
-    const float* V = Q + (long)1536 * ld;
-    const int nslot = (T + 63) >> 6;
-    for (int i = wave; i < T; i += 4) {
-        qs[wave][lane] = Q[(long)lane * ld + i];
-        __builtin_amdgcn_wave_barrier();
-        float sc[8];
-#pragma unroll
-        for (int m = 0; m < 8; ++m) sc[m] = 0.f;
-        for (int d = 0; d < 64; ++d) {
-            const float qd = qs[wave][d];
-            const float* kr = Kp + (long)d * ld;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const int j = lane + 64 * m;
-                if (m < nslot && j < T) sc[m] += qd * kr[j];
-            }
-        }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int j = lane + 64 * m;
-            sc[m] = (m < nslot && j < T) ? sc[m] * 0.125f : -INFINITY;
-            mx = fmaxf(mx, sc[m]);
-        }
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        float sum = 0.f;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int j = lane + 64 * m;
-            if (m < nslot && j < T) {
-                sc[m] = expf(sc[m] - mx);
-                sum += sc[m];
-            }
-        }
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int j = lane + 64 * m;
-            if (m < nslot && j < T) ps[wave][j] = sc[m] / sum;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const float* vr = V + (long)lane * ld;
-        float o = 0.f;
-        for (int j = 0; j < T; ++j) o += ps[wave][j] * vr[j];
-        ctx[b * cbs + (long)(hd * 64 + lane) * cld + i] = o;
-        __builtin_amdgcn_wave_barrier();
-    }
-}
+// qkv [B][2304][ld] = rows [Q | K | V].  ~0.1 % of the model's FLOPs; two LDS forms (T <= 256 and key-blocked).
 // LDS form for T <= 256: K [64][Tp] and V^T [T][65] of the head are staged once per workgroup, so the
 // score and P.V loops read only LDS (lane-contiguous, conflict-free).  Each wave works on TWO query rows at
 // a time (every K / V value read from LDS serves both), and the query rows of one (utterance, head) are
@@ -296,6 +237,128 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(const float* qkv, lo
     }
 }
 
+// Key-blocked LDS form for T > 256 (the reference splits long texts into chunks of up to 500 tokens, so this is the
+// common case there): keys are walked in blocks of 256 whose K [64][256] and V^T [256][65] images are staged once per
+// workgroup; every wave owns PQ query pairs and carries their running maximum, normaliser and output row across the
+// key blocks (online softmax: out = sum_j exp(s_j - m) v_j / sum_j exp(s_j - m), rescaled by exp(m_old - m_new)
+// whenever a block raises the maximum).  Same two-queries-per-wave inner loops as attention_lds_kernel.
+template <int PQ>
+__global__ __launch_bounds__(256) void attention_blocked_kernel(const float* qkv, long bs, int ld, float* ctx, long cbs,
+                                                                int cld, const int* lens, int qsplit) {
+    constexpr int KB = 256;
+    extern __shared__ __attribute__((aligned(16))) float att_smem[];
+    const int b = blockIdx.x / qsplit, qs_id = blockIdx.x - b * qsplit, hd = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int T = lens[b];
+    float* Ks = att_smem;            // [64][KB]
+    float* Vt = Ks + 64 * KB;        // [KB][65]
+    float* ps = Vt + KB * 65;        // [4 waves][2][KB]
+    float* qs = ps + 8 * KB;         // [4 waves][2][64]
+    const float* Q = qkv + b * bs + (long)(hd * 64) * ld;
+    const float* Kp = Q + (long)768 * ld;
+    const float* V = Q + (long)1536 * ld;
+    float* pw0 = ps + (wave * 2) * KB;
+    float* pw1 = pw0 + KB;
+    float* qw0 = qs + (wave * 2) * 64;
+    float* qw1 = qw0 + 64;
+    const int npair = (T + 1) >> 1;
+    const int pair0 = (qs_id * 4 + wave) * PQ;  // this wave's PQ consecutive query pairs
+    float mrun[PQ][2], lrun[PQ][2], orun[PQ][2];
+#pragma unroll
+    for (int pi = 0; pi < PQ; ++pi) {
+        mrun[pi][0] = mrun[pi][1] = -INFINITY;
+        lrun[pi][0] = lrun[pi][1] = 0.f;
+        orun[pi][0] = orun[pi][1] = 0.f;
+    }
+    for (int k0 = 0; k0 < T; k0 += KB) {
+        const int nk = (T - k0) < KB ? (T - k0) : KB;
+        __syncthreads();  // everyone is done with the previous block's images
+        for (int idx = threadIdx.x; idx < 64 * nk; idx += 256) {
+            const int d = idx / nk, j = idx - d * nk;
+            Ks[d * KB + j] = Kp[(long)d * ld + k0 + j];
+            Vt[j * 65 + d] = V[(long)d * ld + k0 + j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pi = 0; pi < PQ; ++pi) {
+            const int pq = pair0 + pi;
+            if (pq >= npair) continue;  // (wave-uniform)
+            const int i0 = 2 * pq, i1 = (2 * pq + 1 < T) ? 2 * pq + 1 : i0;
+            qw0[lane] = Q[(long)lane * ld + i0];
+            qw1[lane] = Q[(long)lane * ld + i1];
+            __builtin_amdgcn_wave_barrier();
+            float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int d = 0; d < 64; ++d) {
+                const float q0 = qw0[d], q1 = qw1[d];
+                const float* kr = Ks + d * KB;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int j = lane + 64 * m;
+                    if (j < nk) {
+                        const float kv = kr[j];
+                        s0[m] += q0 * kv;
+                        s1[m] += q1 * kv;
+                    }
+                }
+            }
+            float mx0 = -INFINITY, mx1 = -INFINITY;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const bool okj = lane + 64 * m < nk;
+                s0[m] = okj ? s0[m] * 0.125f : -INFINITY;
+                s1[m] = okj ? s1[m] * 0.125f : -INFINITY;
+                mx0 = fmaxf(mx0, s0[m]);
+                mx1 = fmaxf(mx1, s1[m]);
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                mx0 = fmaxf(mx0, __shfl_xor(mx0, o));
+                mx1 = fmaxf(mx1, __shfl_xor(mx1, o));
+            }
+            const float mn0 = fmaxf(mrun[pi][0], mx0), mn1 = fmaxf(mrun[pi][1], mx1);
+            const float a0 = expf(mrun[pi][0] - mn0), a1 = expf(mrun[pi][1] - mn1);  // exp(-inf) = 0 on the first block
+            float sum0 = 0.f, sum1 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int j = lane + 64 * m;
+                if (j < nk) {
+                    const float e0 = expf(s0[m] - mn0), e1 = expf(s1[m] - mn1);
+                    pw0[j] = e0;
+                    pw1[j] = e1;
+                    sum0 += e0;
+                    sum1 += e1;
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                sum0 += __shfl_xor(sum0, o);
+                sum1 += __shfl_xor(sum1, o);
+            }
+            __builtin_amdgcn_wave_barrier();
+            float o0 = 0.f, o1 = 0.f;
+            for (int j = 0; j < nk; ++j) {
+                const float vv = Vt[j * 65 + lane];
+                o0 += pw0[j] * vv;
+                o1 += pw1[j] * vv;
+            }
+            mrun[pi][0] = mn0;
+            mrun[pi][1] = mn1;
+            lrun[pi][0] = lrun[pi][0] * a0 + sum0;
+            lrun[pi][1] = lrun[pi][1] * a1 + sum1;
+            orun[pi][0] = orun[pi][0] * a0 + o0;
+            orun[pi][1] = orun[pi][1] * a1 + o1;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+#pragma unroll
+    for (int pi = 0; pi < PQ; ++pi) {
+        const int pq = pair0 + pi;
+        if (pq >= npair) continue;
+        const int i0 = 2 * pq, i1 = (2 * pq + 1 < T) ? 2 * pq + 1 : i0;
+        float* crow = ctx + b * cbs + (long)(hd * 64 + lane) * cld;
+        crow[i0] = orun[pi][0] / lrun[pi][0];
+        if (i1 != i0) crow[i1] = orun[pi][1] / lrun[pi][1];
+    }
+}
+
 void launch_attention(const float* qkv, long bs, int ld, float* ctx, long cbs, int cld, const int* lens, int B,
                       int Tmax, hipStream_t s) {
     KX_REQUIRE(Tmax <= 512, "attention: T > 512");
@@ -313,7 +376,18 @@ void launch_attention(const float* qkv, long bs, int ld, float* ctx, long cbs, i
         hipLaunchKernelGGL(attention_lds_kernel, dim3(B * qsplit, 12), dim3(256), lds, s, qkv, bs, ld, ctx, cbs, cld,
                            lens, qsplit);
     } else {
-        hipLaunchKernelGGL(attention_kernel, dim3(B, 12), dim3(256), 0, s, qkv, bs, ld, ctx, cbs, cld, lens);
+        constexpr int PQ = 4;  // query pairs per wave: 32 query rows per workgroup share one staging of the key blocks
+        const size_t lds = sizeof(float) * ((size_t)64 * 256 + (size_t)256 * 65 + 8 * 256 + 8 * 64);
+        static bool attr_set = false;
+        if (!attr_set) {
+            KX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_blocked_kernel<PQ>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        const int npair_max = (Tmax + 1) / 2;
+        const int qsplit = (npair_max + 4 * PQ - 1) / (4 * PQ);
+        hipLaunchKernelGGL(attention_blocked_kernel<PQ>, dim3(B * qsplit, 12), dim3(256), lds, s, qkv, bs, ld, ctx, cbs, cld,
+                           lens, qsplit);
     }
     KX_HIP(hipGetLastError());
 }
