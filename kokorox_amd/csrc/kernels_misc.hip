@@ -135,260 +135,112 @@ void launch_layernorm_ch(const float* x, float* y, long bs, int ld, int C, LenMa
     KX_HIP(hipGetLastError());
 }
 
-// ---- ALBERT self-attention, 12 heads x 64, T <= 512 ---------------------------------------
-// qkv [B][2304][ld] = rows [Q | K | V].  ~0.1 % of the model's FLOPs; two LDS forms (T <= 256 and key-blocked).
-// LDS form for T <= 256: K [64][Tp] and V^T [T][65] of the head are staged once per workgroup, so the
-// score and P.V loops read only LDS (lane-contiguous, conflict-free).  Each wave works on TWO query rows at
-// a time (every K / V value read from LDS serves both), and the query rows of one (utterance, head) are
-// split over `qsplit` workgroups so that small batches still fill the chip.
-__global__ __launch_bounds__(256) void attention_lds_kernel(const float* qkv, long bs, int ld, float* ctx, long cbs,
-                                                            int cld, const int* lens, int qsplit) {
-    extern __shared__ __attribute__((aligned(16))) float att_smem[];
-    const int b = blockIdx.x / qsplit, qs_id = blockIdx.x - b * qsplit, hd = blockIdx.y;
+// ---- ALBERT self-attention, 12 heads x 64 -----------------------------------------------------
+// qkv [B][2304][ld] = rows [Q | K | V], each [64 dims][time] per head.  Flash-style on the f32 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact f32 products and sums), one wave per tile of 32 query rows, keys in blocks of 32,
+// no LDS and no barriers.  Both products are computed TRANSPOSED so that the query index is the accumulator's
+// column (= lane):
+//   S^T[key][query] = K Q^T   A = K[key][d] (lane = key, 32 coalesced dword loads per block), B = Q (32 registers)
+//   O^T[d][query]  += V^T P^T A = V[d][key] (lane = d, four 16-byte loads per 32 dims), B = P^T
+// The softmax of a query then runs down the lane's own 16 accumulator registers plus one exchange between the two
+// half-waves; the running maximum / normaliser / rescale are per-lane scalars; and since the contraction order of
+// the second product is free, key (s & 3) + 8 (s >> 2) + 4 kk is consumed at step s from half kk - exactly the key
+// that accumulator register s of S^T holds there - so P^T feeds the second MFMA straight from its registers.
+// The output tile stores as whole 128-byte rows of ctx[d][time].
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const float* qkv, long bs, int ld, float* ctx, long cbs,
+                                                             int cld, const int* lens) {
+    using f32x16 = __attribute__((ext_vector_type(16))) float;
+    const int b = blockIdx.x, hd = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, hh = lane >> 5;
     const int T = lens[b];
-    const int Tp = (T + 3) & ~3;
-    float* Ks = att_smem;               // [64][Tp]
-    float* Vt = Ks + 64 * Tp;           // [T][65]
-    float* ps = Vt + T * 65;            // [4 waves][2][Tp]
-    float* qs = ps + 8 * Tp;            // [4 waves][2][64]
+    const int q0 = (blockIdx.z * 4 + wave) * 32;
+    if (q0 >= T) return;  // (no barriers anywhere in this kernel)
     const float* Q = qkv + b * bs + (long)(hd * 64) * ld;
     const float* Kp = Q + (long)768 * ld;
     const float* V = Q + (long)1536 * ld;
-    for (int idx = threadIdx.x; idx < 64 * T; idx += 256) {
-        const int d = idx / T, j = idx - d * T;
-        Ks[d * Tp + j] = Kp[(long)d * ld + j];
-        Vt[j * 65 + d] = V[(long)d * ld + j];
-    }
-    __syncthreads();
-    const int nslot = (T + 63) >> 6;  // <= 4
-    float* pw0 = ps + (wave * 2) * Tp;
-    float* pw1 = pw0 + Tp;
-    float* qw0 = qs + (wave * 2) * 64;
-    float* qw1 = qw0 + 64;
-    const int npair = (T + 1) >> 1;
-    for (int pq = qs_id * 4 + wave; pq < npair; pq += 4 * qsplit) {
-        const int i0 = 2 * pq, i1 = (2 * pq + 1 < T) ? 2 * pq + 1 : i0;
-        qw0[lane] = Q[(long)lane * ld + i0];
-        qw1[lane] = Q[(long)lane * ld + i1];
-        __builtin_amdgcn_wave_barrier();
-        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int d = 0; d < 64; ++d) {
-            const float q0 = qw0[d], q1 = qw1[d];
-            const float* kr = Ks + d * Tp;
+    const int qi = q0 + i < T ? q0 + i : T - 1;
+    float qreg[32];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int j = lane + 64 * m;
-                if (m < nslot && j < T) {
-                    const float kv = kr[j];
-                    s0[m] += q0 * kv;
-                    s1[m] += q1 * kv;
-                }
-            }
+    for (int s = 0; s < 32; ++s) qreg[s] = Q[(long)(2 * s + hh) * ld + qi];
+    f32x16 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o0[e] = o1[e] = 0.f;
+    float mrun = -INFINITY, lrun = 0.f;
+    for (int k0 = 0; k0 < T; k0 += 32) {
+        const int kj = k0 + i < T ? k0 + i : T - 1;
+        f32x16 st;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s)
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(Kp[(long)(2 * s + hh) * ld + kj], qreg[s], st, 0, 0, 0);
+        // lane (query i, half hh), register e: key k0 + (e & 3) + 8 (e >> 2) + 4 hh
+        float bm = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int j = k0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            st[e] = j < T ? st[e] * 0.125f : -INFINITY;
+            bm = fmaxf(bm, st[e]);
         }
-        float mx0 = -INFINITY, mx1 = -INFINITY;
+        bm = fmaxf(bm, __shfl_xor(bm, 32));
+        const float mn = fmaxf(mrun, bm);
+        const float alpha = expf(mrun - mn);  // 0 on the first block
+        float psum = 0.f;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int j = lane + 64 * m;
-            const bool okj = m < nslot && j < T;
-            s0[m] = okj ? s0[m] * 0.125f : -INFINITY;
-            s1[m] = okj ? s1[m] * 0.125f : -INFINITY;
-            mx0 = fmaxf(mx0, s0[m]);
-            mx1 = fmaxf(mx1, s1[m]);
+        for (int e = 0; e < 16; ++e) {
+            st[e] = expf(st[e] - mn);  // exp(-inf) = 0 for masked keys
+            psum += st[e];
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            mx0 = fmaxf(mx0, __shfl_xor(mx0, o));
-            mx1 = fmaxf(mx1, __shfl_xor(mx1, o));
+        psum += __shfl_xor(psum, 32);
+        lrun = lrun * alpha + psum;
+        mrun = mn;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            o0[e] *= alpha;
+            o1[e] *= alpha;
         }
-        float sum0 = 0.f, sum1 = 0.f;
+        // second product: lane = head dim d' (i), half kk (hh): V[d'][k0 + 8 g + 4 kk + 0..3], g = s >> 2
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int j = lane + 64 * m;
-            if (m < nslot && j < T) {
-                s0[m] = expf(s0[m] - mx0);
-                s1[m] = expf(s1[m] - mx1);
-                sum0 += s0[m];
-                sum1 += s1[m];
-            }
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            sum0 += __shfl_xor(sum0, o);
-            sum1 += __shfl_xor(sum1, o);
-        }
+        for (int dt = 0; dt < 2; ++dt) {
+            const float* vrow = V + (long)(dt * 32 + i) * ld + k0 + 4 * hh;
+            float vv[16];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int j = lane + 64 * m;
-            if (m < nslot && j < T) {
-                pw0[j] = s0[m] / sum0;
-                pw1[j] = s1[m] / sum1;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 v4 = *reinterpret_cast<const float4*>(vrow + 8 * g4);  // (rows are 128-byte aligned, ld >= T rounded to 32)
+                const int j = k0 + 8 * g4 + 4 * hh;
+                vv[4 * g4 + 0] = j + 0 < T ? v4.x : 0.f;  // the padding of a row may hold anything
+                vv[4 * g4 + 1] = j + 1 < T ? v4.y : 0.f;
+                vv[4 * g4 + 2] = j + 2 < T ? v4.z : 0.f;
+                vv[4 * g4 + 3] = j + 3 < T ? v4.w : 0.f;
             }
-        }
-        __builtin_amdgcn_wave_barrier();
-        float o0 = 0.f, o1 = 0.f;
-        for (int j = 0; j < T; ++j) {
-            const float vv = Vt[j * 65 + lane];
-            o0 += pw0[j] * vv;
-            o1 += pw1[j] * vv;
-        }
-        float* crow = ctx + b * cbs + (long)(hd * 64 + lane) * cld;
-        crow[i0] = o0;
-        if (i1 != i0) crow[i1] = o1;
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// Key-blocked LDS form for T > 256 (the reference splits long texts into chunks of up to 500 tokens, so this is the
-// common case there): keys are walked in blocks of 256 whose K [64][256] and V^T [256][65] images are staged once per
-// workgroup; every wave owns PQ query pairs and carries their running maximum, normaliser and output row across the
-// key blocks (online softmax: out = sum_j exp(s_j - m) v_j / sum_j exp(s_j - m), rescaled by exp(m_old - m_new)
-// whenever a block raises the maximum).  Same two-queries-per-wave inner loops as attention_lds_kernel.
-template <int PQ>
-__global__ __launch_bounds__(256) void attention_blocked_kernel(const float* qkv, long bs, int ld, float* ctx, long cbs,
-                                                                int cld, const int* lens, int qsplit) {
-    constexpr int KB = 256;
-    extern __shared__ __attribute__((aligned(16))) float att_smem[];
-    const int b = blockIdx.x / qsplit, qs_id = blockIdx.x - b * qsplit, hd = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int T = lens[b];
-    float* Ks = att_smem;            // [64][KB]
-    float* Vt = Ks + 64 * KB;        // [KB][65]
-    float* ps = Vt + KB * 65;        // [4 waves][2][KB]
-    float* qs = ps + 8 * KB;         // [4 waves][2][64]
-    const float* Q = qkv + b * bs + (long)(hd * 64) * ld;
-    const float* Kp = Q + (long)768 * ld;
-    const float* V = Q + (long)1536 * ld;
-    float* pw0 = ps + (wave * 2) * KB;
-    float* pw1 = pw0 + KB;
-    float* qw0 = qs + (wave * 2) * 64;
-    float* qw1 = qw0 + 64;
-    const int npair = (T + 1) >> 1;
-    const int pair0 = (qs_id * 4 + wave) * PQ;  // this wave's PQ consecutive query pairs
-    float mrun[PQ][2], lrun[PQ][2], orun[PQ][2];
 #pragma unroll
-    for (int pi = 0; pi < PQ; ++pi) {
-        mrun[pi][0] = mrun[pi][1] = -INFINITY;
-        lrun[pi][0] = lrun[pi][1] = 0.f;
-        orun[pi][0] = orun[pi][1] = 0.f;
-    }
-    for (int k0 = 0; k0 < T; k0 += KB) {
-        const int nk = (T - k0) < KB ? (T - k0) : KB;
-        __syncthreads();  // everyone is done with the previous block's images
-        for (int idx = threadIdx.x; idx < 64 * nk; idx += 256) {
-            const int d = idx / nk, j = idx - d * nk;
-            Ks[d * KB + j] = Kp[(long)d * ld + k0 + j];
-            Vt[j * 65 + d] = V[(long)d * ld + k0 + j];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int pi = 0; pi < PQ; ++pi) {
-            const int pq = pair0 + pi;
-            if (pq >= npair) continue;  // (wave-uniform)
-            const int i0 = 2 * pq, i1 = (2 * pq + 1 < T) ? 2 * pq + 1 : i0;
-            qw0[lane] = Q[(long)lane * ld + i0];
-            qw1[lane] = Q[(long)lane * ld + i1];
-            __builtin_amdgcn_wave_barrier();
-            float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int d = 0; d < 64; ++d) {
-                const float q0 = qw0[d], q1 = qw1[d];
-                const float* kr = Ks + d * KB;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int j = lane + 64 * m;
-                    if (j < nk) {
-                        const float kv = kr[j];
-                        s0[m] += q0 * kv;
-                        s1[m] += q1 * kv;
-                    }
-                }
+            for (int s = 0; s < 16; ++s) {
+                if (dt == 0)
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[s], st[s], o0, 0, 0, 0);
+                else
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[s], st[s], o1, 0, 0, 0);
             }
-            float mx0 = -INFINITY, mx1 = -INFINITY;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const bool okj = lane + 64 * m < nk;
-                s0[m] = okj ? s0[m] * 0.125f : -INFINITY;
-                s1[m] = okj ? s1[m] * 0.125f : -INFINITY;
-                mx0 = fmaxf(mx0, s0[m]);
-                mx1 = fmaxf(mx1, s1[m]);
-            }
-            for (int o = 32; o > 0; o >>= 1) {
-                mx0 = fmaxf(mx0, __shfl_xor(mx0, o));
-                mx1 = fmaxf(mx1, __shfl_xor(mx1, o));
-            }
-            const float mn0 = fmaxf(mrun[pi][0], mx0), mn1 = fmaxf(mrun[pi][1], mx1);
-            const float a0 = expf(mrun[pi][0] - mn0), a1 = expf(mrun[pi][1] - mn1);  // exp(-inf) = 0 on the first block
-            float sum0 = 0.f, sum1 = 0.f;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int j = lane + 64 * m;
-                if (j < nk) {
-                    const float e0 = expf(s0[m] - mn0), e1 = expf(s1[m] - mn1);
-                    pw0[j] = e0;
-                    pw1[j] = e1;
-                    sum0 += e0;
-                    sum1 += e1;
-                }
-            }
-            for (int o = 32; o > 0; o >>= 1) {
-                sum0 += __shfl_xor(sum0, o);
-                sum1 += __shfl_xor(sum1, o);
-            }
-            __builtin_amdgcn_wave_barrier();
-            float o0 = 0.f, o1 = 0.f;
-            for (int j = 0; j < nk; ++j) {
-                const float vv = Vt[j * 65 + lane];
-                o0 += pw0[j] * vv;
-                o1 += pw1[j] * vv;
-            }
-            mrun[pi][0] = mn0;
-            mrun[pi][1] = mn1;
-            lrun[pi][0] = lrun[pi][0] * a0 + sum0;
-            lrun[pi][1] = lrun[pi][1] * a1 + sum1;
-            orun[pi][0] = orun[pi][0] * a0 + o0;
-            orun[pi][1] = orun[pi][1] * a1 + o1;
-            __builtin_amdgcn_wave_barrier();
         }
     }
+    if (q0 + i < T) {
+        const float inv = 1.0f / lrun;
+        float* cb = ctx + b * cbs + (long)(hd * 64) * cld + q0 + i;
 #pragma unroll
-    for (int pi = 0; pi < PQ; ++pi) {
-        const int pq = pair0 + pi;
-        if (pq >= npair) continue;
-        const int i0 = 2 * pq, i1 = (2 * pq + 1 < T) ? 2 * pq + 1 : i0;
-        float* crow = ctx + b * cbs + (long)(hd * 64 + lane) * cld;
-        crow[i0] = orun[pi][0] / lrun[pi][0];
-        if (i1 != i0) crow[i1] = orun[pi][1] / lrun[pi][1];
+        for (int e = 0; e < 16; ++e) {
+            const int d = (e & 3) + 8 * (e >> 2) + 4 * hh;
+            cb[(long)d * cld] = o0[e] * inv;
+            cb[(long)(32 + d) * cld] = o1[e] * inv;
+        }
     }
 }
 
 void launch_attention(const float* qkv, long bs, int ld, float* ctx, long cbs, int cld, const int* lens, int B,
                       int Tmax, hipStream_t s) {
     KX_REQUIRE(Tmax <= 512, "attention: T > 512");
-    if (Tmax <= 256) {
-        const int Tp = (Tmax + 3) & ~3;
-        const size_t lds = sizeof(float) * ((size_t)64 * Tp + (size_t)Tmax * 65 + 8 * Tp + 8 * 64);
-        static size_t lds_limit = 64 * 1024;
-        if (lds > lds_limit) {
-            KX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_lds_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            lds_limit = lds;
-        }
-        int qsplit = 512 / (B * 12);  // aim at >= 2 workgroups per CU
-        qsplit = qsplit < 1 ? 1 : (qsplit > 8 ? 8 : qsplit);
-        hipLaunchKernelGGL(attention_lds_kernel, dim3(B * qsplit, 12), dim3(256), lds, s, qkv, bs, ld, ctx, cbs, cld,
-                           lens, qsplit);
-    } else {
-        constexpr int PQ = 4;  // query pairs per wave: 32 query rows per workgroup share one staging of the key blocks
-        const size_t lds = sizeof(float) * ((size_t)64 * 256 + (size_t)256 * 65 + 8 * 256 + 8 * 64);
-        static bool attr_set = false;
-        if (!attr_set) {
-            KX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_blocked_kernel<PQ>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
-        const int npair_max = (Tmax + 1) / 2;
-        const int qsplit = (npair_max + 4 * PQ - 1) / (4 * PQ);
-        hipLaunchKernelGGL(attention_blocked_kernel<PQ>, dim3(B * qsplit, 12), dim3(256), lds, s, qkv, bs, ld, ctx, cbs, cld,
-                           lens, qsplit);
-    }
+    KX_REQUIRE(ld % 32 == 0 && ld >= ((Tmax + 31) & ~31), "attention: rows must be padded to a multiple of 32 columns");
+    hipLaunchKernelGGL(attention_mfma_kernel, dim3(B, 12, (Tmax + 127) / 128), dim3(256), 0, s, qkv, bs, ld, ctx, cbs,
+                       cld, lens);
     KX_HIP(hipGetLastError());
 }
 
