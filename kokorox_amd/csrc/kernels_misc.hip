@@ -437,34 +437,51 @@ void launch_copy_rows(const float* src, long sbs, int sld, float* dst, long dbs,
 }
 
 // ---- bidirectional LSTM recurrence (hidden 256) -------------------------------------------
-// gx [B][L][2048] holds W_ih x + b_ih + b_hh for both directions (conv_mfma, time-major
-// store).  One workgroup of 1024 threads per (utterance, direction): thread r owns gate
-// row r, streams W_hh^T[k][r] (coalesced, L2-resident: 1 MB per direction) against h in
-// LDS, then the first 256 threads apply the cell update.
+// gx [B][L][2048] holds W_ih x + b_ih + b_hh for both directions (conv kernel, time-major store).  One workgroup of
+// 1024 threads per (utterance, direction): thread r owns gate row r and walks W_hh^T[k][r] against h in LDS, then
+// the first 256 threads apply the cell update.  A step is bound by how fast one CU can pull the 1 MB of W_hh^T
+// through its L1 (~60 B/clk); the first LSTM_LDS_K of the 256 k-rows therefore stay in LDS for the whole sequence
+// (36 x 4 KB = 144 KB), the rest streams from L2 (coalesced) every step.
+constexpr int LSTM_LDS_K = 36;
 __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gx_bs, int gx_ld, const float* whhT,
                                                     float* y, long y_bs, int y_ld, LenMap len) {
-    __shared__ __attribute__((aligned(16))) float hs[256];
-    __shared__ float gates[1024];
+    extern __shared__ __attribute__((aligned(16))) float lstm_smem[];
+    float* hs = lstm_smem;             // [256]
+    float* gates = hs + 256;           // [1024]
+    float* wl = gates + 1024;          // [LSTM_LDS_K][1024]
     const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
     const int L = len_of(len, b);
     const float* W = whhT + (long)dir * 256 * 1024 + tid;
     float c = 0.f;
     if (tid < 256) hs[tid] = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < LSTM_LDS_K; ++k) wl[k * 1024 + tid] = W[(long)k * 1024];
     __syncthreads();
     for (int step = 0; step < L; ++step) {
         const int t = dir ? (L - 1 - step) : step;
         float acc = gx[b * gx_bs + (long)t * gx_ld + dir * 1024 + tid];
         const float4* h4 = reinterpret_cast<const float4*>(hs);
-#pragma unroll 4
-        for (int k4 = 0; k4 < 64; ++k4) {
+        // streamed part first in program order: its loads are in flight while the LDS part is summed
+        float acc2 = 0.f;
+#pragma unroll 5
+        for (int k4 = LSTM_LDS_K / 4; k4 < 64; ++k4) {
             const float4 hv = h4[k4];
             const float* w = W + (long)k4 * 4 * 1024;
+            acc2 = fmaf(w[0], hv.x, acc2);
+            acc2 = fmaf(w[1024], hv.y, acc2);
+            acc2 = fmaf(w[2048], hv.z, acc2);
+            acc2 = fmaf(w[3072], hv.w, acc2);
+        }
+#pragma unroll
+        for (int k4 = 0; k4 < LSTM_LDS_K / 4; ++k4) {
+            const float4 hv = h4[k4];
+            const float* w = wl + k4 * 4 * 1024 + tid;
             acc = fmaf(w[0], hv.x, acc);
             acc = fmaf(w[1024], hv.y, acc);
             acc = fmaf(w[2048], hv.z, acc);
             acc = fmaf(w[3072], hv.w, acc);
         }
-        gates[tid] = acc;
+        gates[tid] = acc + acc2;
         __syncthreads();
         if (tid < 256) {
             const float ig = 1.0f / (1.0f + expf(-gates[tid]));
@@ -481,7 +498,15 @@ __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gx_bs,
 }
 void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, float* y, long y_bs, int y_ld,
                  LenMap len, int B, hipStream_t s) {
-    hipLaunchKernelGGL(lstm_kernel, dim3(B, 2), dim3(1024), 0, s, gx, gx_bs, gx_ld, whhT, y, y_bs, y_ld, len);
+    static_assert(LSTM_LDS_K % 4 == 0, "whole float4 groups of h");
+    const size_t lds = sizeof(float) * (256 + 1024 + (size_t)LSTM_LDS_K * 1024);
+    static bool attr_set = false;
+    if (!attr_set) {
+        KX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lstm_kernel, dim3(B, 2), dim3(1024), lds, s, gx, gx_bs, gx_ld, whhT, y, y_bs, y_ld, len);
     KX_HIP(hipGetLastError());
 }
 
