@@ -1,4 +1,4 @@
-# A/B harness used for the kernel experiments recorded in DESIGN.md §5: run on the GPU box through gpurun, e.g.
+# A/B harness used for the kernel experiments recorded in DESIGN.md: run on the GPU box through gpurun, e.g.
 #   gpurun -- 'KX_DBG=4 bash tools/ablate.sh'      (KX_DBG bits: 1 no input staging, 2 no weight copies, 4 no MFMAs,
 #                                                   8 no epilogue; KX_LDS_PAD=30000 forces one workgroup per CU)
 # Prints the step time and the per-shape table of the conv launches of one step.
