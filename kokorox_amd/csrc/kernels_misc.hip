@@ -441,8 +441,9 @@ void launch_copy_rows(const float* src, long sbs, int sld, float* dst, long dbs,
 // 1024 threads per (utterance, direction): thread r owns gate row r and walks W_hh^T[k][r] against h in LDS, then
 // the first 256 threads apply the cell update.  A step is bound by how fast one CU can pull the 1 MB of W_hh^T
 // through its L1 (~60 B/clk); the first LSTM_LDS_K of the 256 k-rows therefore stay in LDS for the whole sequence
-// (36 x 4 KB = 144 KB), the rest streams from L2 (coalesced) every step.
+// (36 x 4 KB = 144 KB) and the next LSTM_REG_K in registers, the rest streams from L2 (coalesced) every step.
 constexpr int LSTM_LDS_K = 36;
+constexpr int LSTM_REG_K = 32;  // (64 rows or a deeper unroll of the streamed part: 35-50 % slower steps, the loads serialise)
 __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gx_bs, int gx_ld, const float* whhT,
                                                     float* y, long y_bs, int y_ld, LenMap len) {
     extern __shared__ __attribute__((aligned(16))) float lstm_smem[];
@@ -456,6 +457,10 @@ __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gx_bs,
     if (tid < 256) hs[tid] = 0.f;
 #pragma unroll 4
     for (int k = 0; k < LSTM_LDS_K; ++k) wl[k * 1024 + tid] = W[(long)k * 1024];
+    // ... and the next LSTM_REG_K k-rows in registers (one value per thread and row)
+    float wreg[LSTM_REG_K];
+#pragma unroll
+    for (int k = 0; k < LSTM_REG_K; ++k) wreg[k] = W[(long)(LSTM_LDS_K + k) * 1024];
     __syncthreads();
     for (int step = 0; step < L; ++step) {
         const int t = dir ? (L - 1 - step) : step;
@@ -464,7 +469,7 @@ __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gx_bs,
         // streamed part first in program order: its loads are in flight while the LDS part is summed
         float acc2 = 0.f;
 #pragma unroll 5
-        for (int k4 = LSTM_LDS_K / 4; k4 < 64; ++k4) {
+        for (int k4 = (LSTM_LDS_K + LSTM_REG_K) / 4; k4 < 64; ++k4) {
             const float4 hv = h4[k4];
             const float* w = W + (long)k4 * 4 * 1024;
             acc2 = fmaf(w[0], hv.x, acc2);
@@ -480,6 +485,14 @@ __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gx_bs,
             acc = fmaf(w[1024], hv.y, acc);
             acc = fmaf(w[2048], hv.z, acc);
             acc = fmaf(w[3072], hv.w, acc);
+        }
+#pragma unroll
+        for (int k4 = 0; k4 < LSTM_REG_K / 4; ++k4) {
+            const float4 hv = h4[LSTM_LDS_K / 4 + k4];
+            acc = fmaf(wreg[4 * k4 + 0], hv.x, acc);
+            acc = fmaf(wreg[4 * k4 + 1], hv.y, acc);
+            acc = fmaf(wreg[4 * k4 + 2], hv.z, acc);
+            acc = fmaf(wreg[4 * k4 + 3], hv.w, acc);
         }
         gates[tid] = acc + acc2;
         __syncthreads();
@@ -498,7 +511,7 @@ __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gx_bs,
 }
 void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, float* y, long y_bs, int y_ld,
                  LenMap len, int B, hipStream_t s) {
-    static_assert(LSTM_LDS_K % 4 == 0, "whole float4 groups of h");
+    static_assert(LSTM_LDS_K % 4 == 0 && LSTM_REG_K % 4 == 0, "whole float4 groups of h");
     const size_t lds = sizeof(float) * (256 + 1024 + (size_t)LSTM_LDS_K * 1024);
     static bool attr_set = false;
     if (!attr_set) {
