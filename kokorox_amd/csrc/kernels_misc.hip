@@ -22,11 +22,11 @@ void launch_vec_add(const float* a, const float* b, float* out, int n, hipStream
     KX_HIP(hipGetLastError());
 }
 
-__global__ void transpose_whh_kernel(const float* w, float* out) {  // [1024][256] -> [256][1024]
+__global__ void transpose_whh_kernel(const float* w, float* out) {  // [1024 rows][256 k] -> [64 k4][1024 rows][4 k]
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 1024 * 256) {
         int r = i / 256, k = i % 256;
-        out[k * 1024 + r] = w[i];
+        out[((k >> 2) * 1024 + r) * 4 + (k & 3)] = w[i];
     }
 }
 void launch_transpose_whh(const float* whh, float* out, hipStream_t s) {
@@ -447,52 +447,53 @@ constexpr int LSTM_REG_K = 32;  // (64 rows or a deeper unroll of the streamed p
 __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gx_bs, int gx_ld, const float* whhT,
                                                     float* y, long y_bs, int y_ld, LenMap len) {
     extern __shared__ __attribute__((aligned(16))) float lstm_smem[];
-    float* hs = lstm_smem;             // [256]
-    float* gates = hs + 256;           // [1024]
-    float* wl = gates + 1024;          // [LSTM_LDS_K][1024]
+    float* hs = lstm_smem;                                          // [256]
+    float* gates = hs + 256;                                        // [1024]
+    float4* wl = reinterpret_cast<float4*>(gates + 1024);           // [LSTM_LDS_K / 4][1024] x 4 k
     const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
     const int L = len_of(len, b);
-    const float* W = whhT + (long)dir * 256 * 1024 + tid;
+    // image [k4][row][4 k]: thread = row, every access is one 16-byte piece, coalesced across the workgroup
+    const float4* W4 = reinterpret_cast<const float4*>(whhT + (long)dir * 256 * 1024) + tid;
     float c = 0.f;
     if (tid < 256) hs[tid] = 0.f;
-#pragma unroll 4
-    for (int k = 0; k < LSTM_LDS_K; ++k) wl[k * 1024 + tid] = W[(long)k * 1024];
-    // ... and the next LSTM_REG_K k-rows in registers (one value per thread and row)
-    float wreg[LSTM_REG_K];
 #pragma unroll
-    for (int k = 0; k < LSTM_REG_K; ++k) wreg[k] = W[(long)(LSTM_LDS_K + k) * 1024];
+    for (int k4 = 0; k4 < LSTM_LDS_K / 4; ++k4) wl[k4 * 1024 + tid] = W4[(long)k4 * 1024];
+    // ... and the next LSTM_REG_K k-rows in registers
+    float4 wreg[LSTM_REG_K / 4];
+#pragma unroll
+    for (int k4 = 0; k4 < LSTM_REG_K / 4; ++k4) wreg[k4] = W4[(long)(LSTM_LDS_K / 4 + k4) * 1024];
     __syncthreads();
     for (int step = 0; step < L; ++step) {
         const int t = dir ? (L - 1 - step) : step;
         float acc = gx[b * gx_bs + (long)t * gx_ld + dir * 1024 + tid];
         const float4* h4 = reinterpret_cast<const float4*>(hs);
-        // streamed part first in program order: its loads are in flight while the LDS part is summed
+        // streamed part first in program order: its loads are in flight while the resident parts are summed
         float acc2 = 0.f;
-#pragma unroll 5
+#pragma unroll 8
         for (int k4 = (LSTM_LDS_K + LSTM_REG_K) / 4; k4 < 64; ++k4) {
             const float4 hv = h4[k4];
-            const float* w = W + (long)k4 * 4 * 1024;
-            acc2 = fmaf(w[0], hv.x, acc2);
-            acc2 = fmaf(w[1024], hv.y, acc2);
-            acc2 = fmaf(w[2048], hv.z, acc2);
-            acc2 = fmaf(w[3072], hv.w, acc2);
+            const float4 w = W4[(long)k4 * 1024];
+            acc2 = fmaf(w.x, hv.x, acc2);
+            acc2 = fmaf(w.y, hv.y, acc2);
+            acc2 = fmaf(w.z, hv.z, acc2);
+            acc2 = fmaf(w.w, hv.w, acc2);
         }
 #pragma unroll
         for (int k4 = 0; k4 < LSTM_LDS_K / 4; ++k4) {
             const float4 hv = h4[k4];
-            const float* w = wl + k4 * 4 * 1024 + tid;
-            acc = fmaf(w[0], hv.x, acc);
-            acc = fmaf(w[1024], hv.y, acc);
-            acc = fmaf(w[2048], hv.z, acc);
-            acc = fmaf(w[3072], hv.w, acc);
+            const float4 w = wl[k4 * 1024 + tid];
+            acc = fmaf(w.x, hv.x, acc);
+            acc = fmaf(w.y, hv.y, acc);
+            acc = fmaf(w.z, hv.z, acc);
+            acc = fmaf(w.w, hv.w, acc);
         }
 #pragma unroll
         for (int k4 = 0; k4 < LSTM_REG_K / 4; ++k4) {
             const float4 hv = h4[LSTM_LDS_K / 4 + k4];
-            acc = fmaf(wreg[4 * k4 + 0], hv.x, acc);
-            acc = fmaf(wreg[4 * k4 + 1], hv.y, acc);
-            acc = fmaf(wreg[4 * k4 + 2], hv.z, acc);
-            acc = fmaf(wreg[4 * k4 + 3], hv.w, acc);
+            acc = fmaf(wreg[k4].x, hv.x, acc);
+            acc = fmaf(wreg[k4].y, hv.y, acc);
+            acc = fmaf(wreg[k4].z, hv.z, acc);
+            acc = fmaf(wreg[k4].w, hv.w, acc);
         }
         gates[tid] = acc + acc2;
         __syncthreads();

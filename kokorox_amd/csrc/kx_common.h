@@ -122,7 +122,7 @@ void launch_pack_convT16(const float* w, void* dst, int Cin, int Cout, int sd, i
 
 // ---- everything else (kernels_misc.hip) ----------------------------------------------
 void launch_vec_add(const float* a, const float* b, float* out, int n, hipStream_t s);
-void launch_transpose_whh(const float* whh, float* out, hipStream_t s);  // [1024][256] -> [256][1024]
+void launch_transpose_whh(const float* whh, float* out, hipStream_t s);  // [1024 rows][256 k] -> [64][1024][4 k]
 
 void launch_albert_embed(const int64_t* ids, long ids_stride, const float* word, const float* type0,
                          const float* pos, float* out, long bs, int ld, const int* lens, int B, int Tmax,
