@@ -441,9 +441,11 @@ void launch_copy_rows(const float* src, long sbs, int sld, float* dst, long dbs,
 // 1024 threads per (utterance, direction): thread r owns gate row r and walks W_hh^T[k][r] against h in LDS, then
 // the first 256 threads apply the cell update.  A step is bound by how fast one CU can pull the 1 MB of W_hh^T
 // through its L1 (~60 B/clk); the first LSTM_LDS_K of the 256 k-rows therefore stay in LDS for the whole sequence
-// (36 x 4 KB = 144 KB) and the next LSTM_REG_K in registers, the rest streams from L2 (coalesced) every step.
+// (36 x 4 KB = 144 KB) and the next LSTM_REG_K in registers, the rest streams from L2 every step.  The image is
+// [k/4][row][4 k], so every thread moves 16-byte pieces (a quarter of the load instructions of a [k][row] image:
+// the step got 20 % shorter; with 4-byte loads, more than 32 register rows made it 35-50 % longer).
 constexpr int LSTM_LDS_K = 36;
-constexpr int LSTM_REG_K = 32;  // (64 rows or a deeper unroll of the streamed part: 35-50 % slower steps, the loads serialise)
+constexpr int LSTM_REG_K = 64;
 __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gx_bs, int gx_ld, const float* whhT,
                                                     float* y, long y_bs, int y_ld, LenMap len) {
     extern __shared__ __attribute__((aligned(16))) float lstm_smem[];
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gx_bs,
         const float4* h4 = reinterpret_cast<const float4*>(hs);
         // streamed part first in program order: its loads are in flight while the resident parts are summed
         float acc2 = 0.f;
-#pragma unroll 8
+#pragma unroll 4
         for (int k4 = (LSTM_LDS_K + LSTM_REG_K) / 4; k4 < 64; ++k4) {
             const float4 hv = h4[k4];
             const float4 w = W4[(long)k4 * 1024];
