@@ -29,7 +29,6 @@ using half2v = __attribute__((ext_vector_type(2))) _Float16;
 #endif
 constexpr int EPI_ROWS = KX_EPI_ROWS;  // rows per epilogue load batch
 constexpr int CK16 = 16;  // input channels per K-chunk
-constexpr int TK_MAX = 3;  // taps per weight piece in LDS (template parameter TK <= this)
 
 // sin^2(t) for moderate |t| (snake activations).  sin^2 has period pi and is even about every multiple of it, so
 // one Cody-Waite reduction to r = t - n pi, |r| <= pi/2, and one even polynomial do the whole job, with no quadrant
@@ -112,7 +111,6 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
     // LDS carve (16-B units): two weight-piece buffers, then Xs [hi|lo][octet][XWp]
     uint4* Wbuf = reinterpret_cast<uint4*>(smem16);
     uint4* Xs = Wbuf + 2 * piece_units;
-    unsigned* Xs32 = reinterpret_cast<unsigned*>(Xs);
 
     f32x16 acc[MT][NT];
 #pragma unroll
