@@ -20,14 +20,17 @@ __device__ __forceinline__ float dpp_add(float x) {
     const int moved = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true);
     return x + __builtin_bit_cast(float, moved);
 }
-// sum over the 32 lanes of a half-wave, result in every lane: xor-1, xor-2 (quad_perm), half-mirror and
-// mirror inside each row of 16, then one cross-row exchange
+// sum over the 32 lanes of a half-wave, all on the vector unit: xor-1, xor-2 (quad_perm), half-mirror and mirror
+// inside each row of 16, then row_bcast15 (lane 15 of rows 0 / 2 added into every lane of rows 1 / 3).  The total is
+// valid in the UPPER 16 lanes of each half-wave (lanes 16-31 and 48-63).
+constexpr int HALF_WAVE_SUM_LANE = 16;  // r = lane & 31 of a lane that holds the total
 __device__ __forceinline__ float half_wave_sum(float x) {
     x = dpp_add<0xB1>(x);   // quad_perm [1,0,3,2]
     x = dpp_add<0x4E>(x);   // quad_perm [2,3,0,1]
     x = dpp_add<0x141>(x);  // row_half_mirror
     x = dpp_add<0x140>(x);  // row_mirror
-    return x + __shfl_xor(x, 16);
+    const int up = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xa, 0xf, false);  // row_bcast15
+    return x + __builtin_bit_cast(float, up);
 }
 
 // v / d for a launch-constant divisor, rd = 1 / d: one Newton step on the product makes the quotient correctly
@@ -190,7 +193,7 @@ __device__ __forceinline__ void conv_store_rmw(const ConvArgs& a, f32x16 (&acc)[
                 // fused InstanceNorm statistics of what was just stored: reduce the row's partial over the 32 lanes
                 // of this half-wave (lanes = columns), one (sum, sumsq) per row and column slot
                 const float sv = half_wave_sum(rs), qv = half_wave_sum(rq);
-                if (r == 0 && rok)
+                if (r == HALF_WAVE_SUM_LANE && rok)
                     a.stat_part[((long)b * a.Cout + rowu + 4 * h) * a.stat_tiles + stat_slot] = make_float2(sv, qv);
             }
         }
