@@ -188,6 +188,11 @@ int kx_test_lstm(int device_id, const float* x, int B, int L, int n_in, const fl
                  const float* w_hh_r, const float* b_ih_r, const float* b_hh_r, float* y,
                  char* err, size_t err_len);
 
+/* Stand-alone ALBERT self-attention (12 heads x 64): qkv [B][2304][T] (rows Q | K | V, head-major, time
+ * contiguous) with per-utterance valid lengths -> ctx [B][768][T]; columns >= lens[b] are left untouched. */
+int kx_test_attention(int device_id, const float* qkv, const int32_t* lens, int B, int T, float* ctx,
+                      char* err, size_t err_len);
+
 /* Stand-alone harmonic source: f0 [B, 2F] -> har_source [B, 600F] (bit-exact phase). */
 int kx_test_source(int device_id, const float* f0, int B, int F2, const float* lin_w,
                    float lin_b, uint64_t seed, uint64_t utt_base, int noise_off, float* out,

@@ -1,6 +1,8 @@
 // extern "C" surface of libkokorox_hip.so (include/kokorox_hip.h).  Nothing throws across it.
+#include <cmath>
 #include <cstring>
 #include <memory>
+#include <vector>
 
 #include "../../include/kokorox_hip.h"
 #include "model.h"
@@ -382,6 +384,33 @@ int kx_test_lstm(int device_id, const float* x, int B, int L, int n_in, const fl
         for (int b = 0; b < B; ++b)
             for (int c = 0; c < 512; ++c)
                 for (int t = 0; t < L; ++t) y[((size_t)b * L + t) * 512 + c] = yc[((size_t)b * 512 + c) * L + t];
+    });
+}
+
+int kx_test_attention(int device_id, const float* qkv, const int32_t* lens, int B, int T, float* ctx, char* err,
+                      size_t err_len) {
+    return guarded_free(err, err_len, [&] {
+        check_device(device_id);
+        KX_REQUIRE(qkv && lens && ctx && B > 0 && T > 0 && T <= 512, "test_attention: bad argument");
+        for (int b = 0; b < B; ++b) KX_REQUIRE(lens[b] >= 1 && lens[b] <= T, "test_attention: lens out of range");
+        KX_HIP(hipSetDevice(device_id));
+        DevMem dm;
+        const int ld = (T + 31) & ~31;  // rows padded as in the model (128-byte lines)
+        std::vector<float> q((size_t)B * 2304 * ld, std::nanf(""));  // padding holds NaNs: the kernel must not use it
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < 2304; ++c)
+                std::memcpy(&q[((size_t)b * 2304 + c) * ld], &qkv[((size_t)b * 2304 + c) * T], (size_t)T * 4);
+        const float* d_q = dm.up(q.data(), q.size());
+        const int* d_len = dm.up(lens, B);
+        float* d_ctx = dm.get<float>((size_t)B * 768 * ld);
+        KX_HIP(hipMemset(d_ctx, 0, (size_t)B * 768 * ld * 4));
+        kx::launch_attention(d_q, (long)2304 * ld, ld, d_ctx, (long)768 * ld, ld, d_len, B, T, nullptr);
+        KX_HIP(hipDeviceSynchronize());
+        std::vector<float> c((size_t)B * 768 * ld);
+        KX_HIP(hipMemcpy(c.data(), d_ctx, c.size() * 4, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b)
+            for (int r = 0; r < 768; ++r)
+                std::memcpy(&ctx[((size_t)b * 768 + r) * T], &c[((size_t)b * 768 + r) * ld], (size_t)T * 4);
     });
 }
 

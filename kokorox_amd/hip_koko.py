@@ -96,6 +96,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                  i32, i32, cp, sz]),
         "kx_test_lstm": (i32, [i32, vp, i32, i32, i32] + [vp] * 9 + [cp, sz]),
         "kx_test_source": (i32, [i32, vp, i32, i32, vp, f32, u64, u64, i32, vp, cp, sz]),
+        "kx_test_attention": (i32, [i32, vp, vp, i32, i32, vp, cp, sz]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = the ABI lost a symbol
@@ -112,7 +113,7 @@ ABI_SYMBOLS = [
     "kx_set_conv_mode", "kx_get_conv_mode",
     "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_set_voice_table", "kx_infer_voices",
     "kx_infer_packed", "kx_free_packed", "kx_dispatcher_create", "kx_dispatcher_submit",
-    "kx_dispatcher_stats", "kx_dispatcher_destroy", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source",
+    "kx_dispatcher_stats", "kx_dispatcher_destroy", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test_attention",
 ]
 
 
@@ -411,6 +412,18 @@ def lstm(x, params, device=0):
     y = np.zeros((B, L, 512), dtype=np.float32)
     _err_call(lib.kx_test_lstm, device, _ptr(x), B, L, n_in, *[_ptr(p) for p in ps], _ptr(y))
     return y
+
+
+def attention(qkv, lens, device=0):
+    """qkv [B,2304,T] (rows Q|K|V, 12 heads x 64 each), lens [B] -> ctx [B,768,T] (ALBERT self-attention)."""
+    lib = load_library()
+    qkv = _f32(qkv)
+    B, C, T = qkv.shape
+    assert C == 2304
+    lens = np.ascontiguousarray(np.asarray(lens, dtype=np.int32))
+    ctx = np.zeros((B, 768, T), dtype=np.float32)
+    _err_call(lib.kx_test_attention, device, _ptr(qkv), _ptr(lens), B, T, _ptr(ctx))
+    return ctx
 
 
 def harmonic_source(f0, lin_w, lin_b, seed=0, utt_base=0, noise_off=False, device=0):

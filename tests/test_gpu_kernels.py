@@ -115,3 +115,39 @@ def test_harmonic_source_phase_is_bit_faithful(oracle):
     y0 = hk.harmonic_source(f0[:1], lw, lb, seed=7, utt_base=5, noise_off=True)
     ref0 = oracle.source(torch.from_numpy(f0[0]), 7, 5, 0.0, {}).numpy()
     assert np.abs(y0[0] - ref0).max() < 2e-6
+
+
+# ---- ALBERT self-attention hook (attention_mfma_kernel) vs a float64 softmax -----------------------------------
+def _attention_ref(qkv, lens):
+    B, _, T = qkv.shape
+    out = np.zeros((B, 768, T), dtype=np.float64)
+    q64 = qkv.astype(np.float64)
+    for b in range(B):
+        L = int(lens[b])
+        for hd in range(12):
+            Q = q64[b, hd * 64:(hd + 1) * 64, :L]            # [64, L]
+            K = q64[b, 768 + hd * 64:768 + (hd + 1) * 64, :L]
+            V = q64[b, 1536 + hd * 64:1536 + (hd + 1) * 64, :L]
+            S = (Q.T @ K) * 0.125                               # [query, key]
+            S -= S.max(axis=1, keepdims=True)
+            P = np.exp(S)
+            P /= P.sum(axis=1, keepdims=True)
+            out[b, hd * 64:(hd + 1) * 64, :L] = (P @ V.T).T
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,lens", [(1, [1]), (33, [33, 1, 32]), (130, [130, 97, 64, 5]), (300, [300, 257, 31]),
+                                     (512, [512, 449])])
+def test_attention_matches_float64_softmax(T, lens):
+    from kokorox_amd import hip_koko
+    rng = np.random.default_rng(1000 + T)
+    B = len(lens)
+    qkv = rng.standard_normal((B, 2304, T)).astype(np.float32)
+    qkv[:, :1536] *= 1.5                                        # sharper softmax than unit-variance scores give
+    got = hip_koko.attention(qkv, lens)
+    ref = _attention_ref(qkv, lens)
+    for b, L in enumerate(lens):
+        err = np.abs(got[b, :, :L] - ref[b, :, :L]).max()
+        assert err < 2e-5, (b, L, err)
+        assert np.all(got[b, :, L:] == 0.0)                     # columns past the utterance are not written
