@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--cpu-utts", type=int, default=12, help="utterances in the CPU baseline sample (0 = skip)")
     ap.add_argument("--detail", default="", help="write a per-shape table of the conv launches to this file")
     ap.add_argument("--free-run", type=int, default=1, help="also time one step with predicted durations")
+    ap.add_argument("--pcie", type=int, default=1, help="also time one step through the host-buffer boundary (N=1)")
     a = ap.parse_args()
 
     import faulthandler
@@ -276,6 +277,22 @@ def main():
                 "rtf_rank0": sf * 600 / 24000.0 / w1}
         del buf
 
+    # ---- the same batch through the host-buffer boundary (kx_infer: H2D of ids/styles, forward, D2H of the audio) ----
+    pcie = None
+    if a.pcie and rank == 0 and world == 1:
+        model.set_pinned_durations([3, 3, 3, 4])
+        toks = [row.tolist() for row in ids.cpu().numpy()]
+        st_h = styles.cpu().numpy()
+        model.infer_batch(toks, st_h, speeds, seed=2)  # untimed: I/O arena at this shape
+        t2 = time.perf_counter()
+        outs = model.infer_batch(toks, st_h, speeds, seed=2)
+        w2 = time.perf_counter() - t2
+        a_s = sum(len(o) for o in outs) / 24000.0
+        pcie = {"rtf": a_s / w2, "ms_per_step": w2 * 1e3, "audio_s": a_s,
+                "note": "host buffers in and out (pageable), incl. the ctypes marshalling of this script"}
+        progress(f"host-buffer step: {w2:.3f} s")
+        del outs
+
     if rank == 0:
         flops_per_utt = (0.1635 * T + 1.317 * F) * 1e9  # SURVEY.md §8d model
         out = {
@@ -304,6 +321,7 @@ def main():
             "model_tflops": flops_per_utt * world * B * a.steps / wall / 1e12,
             "roofline": roofline(f16x3, conv_flops, conv_ms, n_launch, a.steps, wall, B, T, F),
             "free_running": free,
+            "pcie_inclusive": pcie,
         }
         if world == 1 and a.cpu_utts > 0:
             out["cpu_baseline"] = cpu_baseline(blob_path, a.cpu_utts, a.phonemes, pinned)
