@@ -6,6 +6,7 @@ Reference (paths under /root/reference/kokorox/src/tts/):
   * `TTSKoko::load_voices`  koko.rs:1308-1334  — NPZ -> {name: [511][1][256]}
   * `tokenize_with_variant` tokenize.rs:35-67  — char -> id, unknown chars dropped
   * padding                 koko.rs:1161-1175  — optional id-30 prefix, 0 at both ends
+  * chunk loop              koko.rs:947-1191   — one forward per <= 500-token chunk, waveforms appended
 These stay on the host (north_star: "the voice-style mixer ... stay identical"); the GPU
 only ever sees ids and one 256-float row per utterance.
 """
@@ -75,3 +76,28 @@ def pad_tokens(tokens: Sequence[int], initial_silence: int = 0) -> List[List[int
     """koko.rs:1161-1175: optional id-30 prefix, then 0 at both ends, as a batch of one."""
     t = [30] * int(initial_silence) + list(tokens)
     return [[0] + t + [0]]
+
+
+def tts_chunks(model, styles: Dict[str, np.ndarray], style_name: str, chunk_tokens: Sequence[Sequence[int]],
+               speed: float = 1.0, initial_silence: int = 0, seed: int = 0) -> np.ndarray:
+    """Mirror of the chunk loop of `TTSKoko::tts_raw_audio` (koko.rs:947-1191, SURVEY §8 row a8) from the point
+    where a chunk has been tokenised: per chunk the optional id-30 prefix, `mix_styles(style, tokens.len())` (the
+    style row depends on the chunk's own token count, koko.rs:1165), zero padding at both ends, one forward, and
+    the waveforms appended one after the other with no cross-fade (koko.rs:1177-1180).
+
+    The reference runs the chunks one by one through its single `Mutex<Session>`; chunks are independent, so here
+    they form ONE batched forward (`model.infer_batch`), which on the GPU gives the same samples as chunk-by-chunk
+    calls (utterance b of a batch draws its noise from key (seed, b): tests/test_gpu_forward.py).  An empty chunk
+    list gives an empty waveform; an empty chunk is an error, as `OrtKoko::infer` would index past the end
+    (ort_koko.rs:56)."""
+    toks, rows = [], []
+    for ch in chunk_tokens:
+        t = [30] * int(initial_silence) + [int(v) for v in ch]
+        if not t:
+            raise ValueError("tts_chunks: empty chunk")
+        rows.append(mix_styles(styles, style_name, len(t))[0])
+        toks.append([0] + t + [0])
+    if not toks:
+        return np.zeros(0, dtype=np.float32)
+    outs = model.infer_batch(toks, np.asarray(rows, dtype=np.float32), [float(speed)], seed=seed)
+    return np.concatenate([np.asarray(o, dtype=np.float32) for o in outs])

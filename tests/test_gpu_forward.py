@@ -201,3 +201,27 @@ def test_device_blob_constructor_matches_file_constructor(hip_model, blob_path):
     b = m2.infer([list(ids[0])], [list(styles[0])], 1.0, seed=4)
     m2.close()
     np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_chunks_of_a_long_text_batched_equal_chunk_by_chunk(hip_model):
+    """SURVEY §8 row a8 (koko.rs:947-1191): the reference runs the chunks of a long text one after the other; the
+    host mirror batches them.  Chunk b of the batch draws its noise from key (seed, b), so it must equal, bit for
+    bit, a batch-of-one call whose utterance base is b."""
+    from kokorox_amd import voices as V
+    from kokorox_amd import weights as W
+
+    table = {"af_sky": W.synthetic_voices(2)[0], "af_nicole": W.synthetic_voices(2)[1]}
+    rng = np.random.default_rng(77)
+    chunks = [rng.integers(1, 178, size=n).tolist() for n in (41, 7, 120)]
+    style = "af_sky.4+af_nicole.5"
+    whole = V.tts_chunks(hip_model, table, style, chunks, speed=1.0, initial_silence=1, seed=11)
+    parts = []
+    for b, ch in enumerate(chunks):
+        t = [30] + ch
+        hip_model.set_utterance_base(b)
+        parts.append(hip_model.infer([[0] + t + [0]], V.mix_styles(table, style, len(t)), 1.0, seed=11))
+    hip_model.set_utterance_base(0)
+    ref = np.concatenate(parts)
+    assert whole.shape == ref.shape and whole.shape[0] > 24000
+    assert np.array_equal(whole, ref)

@@ -193,3 +193,26 @@ def test_importer_reads_safetensors(tmp_path):
     r = I.read_safetensors(p)
     np.testing.assert_array_equal(r["x.weight"], a["x.weight"])
     np.testing.assert_array_equal(r["y.bias"], a["y.bias"].astype(np.float32))
+
+
+def test_tts_chunks_builds_the_reference_calls():
+    """per chunk id-30 prefix, style row picked by the chunk's own token count, 0 ... 0 padding,
+    waveforms appended in order (koko.rs:1161-1180)."""
+    from kokorox_amd import voices as V
+
+    table = {"af": np.arange(511 * 256, dtype=np.float32).reshape(511, 1, 256)}
+    calls = {}
+
+    class FakeModel:
+        def infer_batch(self, tokens, styles, speeds, seed=0, flags=0):
+            calls["tokens"], calls["styles"], calls["speeds"], calls["seed"] = tokens, np.asarray(styles), speeds, seed
+            return [np.full(len(t), float(i), dtype=np.float32) for i, t in enumerate(tokens)]
+
+    out = V.tts_chunks(FakeModel(), table, "af", [[5, 6, 7], [9]], speed=1.25, initial_silence=2, seed=7)
+    assert calls["tokens"] == [[0, 30, 30, 5, 6, 7, 0], [0, 30, 30, 9, 0]]
+    assert np.array_equal(calls["styles"][0], table["af"][5, 0]) and np.array_equal(calls["styles"][1], table["af"][3, 0])
+    assert calls["speeds"] == [1.25] and calls["seed"] == 7
+    assert np.array_equal(out, np.concatenate([np.zeros(7, np.float32), np.ones(5, np.float32)]))
+    assert V.tts_chunks(FakeModel(), table, "af", []).shape == (0,)
+    with pytest.raises(ValueError):
+        V.tts_chunks(FakeModel(), table, "af", [[]])
