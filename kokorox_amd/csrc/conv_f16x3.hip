@@ -454,10 +454,22 @@ static void launch_inst16(const ConvArgs& a, int B, int max_cols, hipStream_t s)
     launch_inst16_tk<BM, BN, WM, WN, 3>(a, B, max_cols, s);
 }
 
-int conv16_pick_bn(int BM, int max_cols) {
+// Tile of a launch: BN columns per workgroup, WN = waves side by side along the columns.
+//   128-row weights: 256 x (2 x 2 waves) by default; 128 x (2 x 2) for short sequences; and for small grids (batch 1:
+//   256-column tiles would not even give every CU one workgroup) 128 x (4 x 1): half the tile, but each wave still
+//   spans 128 columns, so the fused InstanceNorm partial sums cover the same column groups in the same order as with
+//   the 256-wide tile and results stay bit-identical across batch sizes.
+void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int* bn, int* wn) {
     static const int force = env_int("KX_BN", 0);
-    if (BM == 128 && force == 128) return 128;
-    return (BM == 128 && max_cols <= 160) ? 128 : 256;
+    if (BM != 128) {
+        *bn = 256; *wn = 4;
+    } else if (force == 128 || max_cols <= 160) {
+        *bn = 128; *wn = 2;
+    } else if ((long)((max_cols + 255) / 256) * ((Cout + 127) / 128) * B < 256 && force != 256) {
+        *bn = 128; *wn = 1;
+    } else {
+        *bn = 256; *wn = 2;
+    }
 }
 
 void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStream_t s) {
@@ -477,7 +489,11 @@ void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStre
             return;
         }
         KX_REQUIRE(a.epi != EPI_GELU_NEW, "conv1d f16x3: gelu epilogue exists only for k=1 GEMMs with >= 48 input channels");
-        if (conv16_pick_bn(BM, max_cols) == 128)
+        int bn, wn;
+        conv16_pick_tile(BM, max_cols, B, a.Cout, &bn, &wn);
+        if (bn == 128 && wn == 1)
+            launch_inst16<128, 128, 4, 1>(a, B, max_cols, s);
+        else if (bn == 128)
             launch_inst16<128, 128, 2, 2>(a, B, max_cols, s);
         else
             launch_inst16<128, 256, 2, 2>(a, B, max_cols, s);

@@ -113,7 +113,7 @@ size_t packed_conv_floats(int rows, int Cin, int K, int BM);
 // f16x3 split path
 enum ConvMode { CONV_F32 = 0, CONV_F16X3 = 1 };
 void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStream_t s);
-int conv16_pick_bn(int BM, int max_cols);
+void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int* bn, int* wn);  // (conv_f16x3.hip)
 size_t packed_conv16_halves(int rows, int Cin, int K, int BM);
 float device_absmax(const float* p, long n, hipStream_t s);
 int pick_weight_shift(float absmax);

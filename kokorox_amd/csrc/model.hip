@@ -393,8 +393,7 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
         const int max_c = out.Lmax;
         int bn, wn;
         if (conv_mode == CONV_F16X3) {
-            bn = w.BM == 128 ? conv16_pick_bn(w.BM, max_c) : 256;
-            wn = w.BM == 128 ? 2 : 4;
+            conv16_pick_tile(w.BM, max_c, B_, w.rows, &bn, &wn);
         } else {
             bn = conv_bn(w.BM);
             wn = w.BM == 128 ? 2 : 4;
