@@ -151,6 +151,9 @@ class Model {
     void ensure_arena(Arena& a, size_t bytes);
 
     hipStream_t stream_ = nullptr;
+    // side stream for the TextEncoder branch, which does not depend on the ALBERT / duration branch
+    hipStream_t stream2_ = nullptr;
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     char* blob_ = nullptr;
     size_t blob_bytes_ = 0;
     std::map<std::string, TensorInfo> table_;

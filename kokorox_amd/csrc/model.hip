@@ -17,17 +17,24 @@ Model::Model(int dev) : device(dev) {
     if (const char* e = getenv("KOKOROX_CONV")) conv_mode = (strcmp(e, "f32") == 0) ? CONV_F32 : CONV_F16X3;
     KX_HIP(hipSetDevice(device));
     KX_HIP(hipStreamCreate(&stream_));
+    KX_HIP(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+    KX_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    KX_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     init_dft_tables();
 }
 
 Model::~Model() {
     (void)hipSetDevice(device);
     if (stream_) (void)hipStreamSynchronize(stream_);
+    if (stream2_) (void)hipStreamSynchronize(stream2_);
     for (void* p : owned_) (void)hipFree(p);
     for (Arena* a : {&arenaT_, &arenaF_, &arenaIO_})
         if (a->base) (void)hipFree(a->base);
     if (blob_) (void)hipFree(blob_);
     for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
+    if (stream2_) (void)hipStreamDestroy(stream2_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -672,7 +679,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     const int noise_off = (flags & 1u) ? 1 : 0;
 
     // ===== front half: everything on the token axis ==========================================
-    float *emb, *h, *qkv, *ctx, *av, *ff, *dcat, *gxT, *xl, *logits, *te0, *te1, *t_en, *d_speeds;
+    float *emb, *h, *qkv, *ctx, *av, *ff, *dcat, *gxT, *gxT2, *xl, *logits, *te0, *te1, *t_en, *d_speeds;
     int *dur, *idx;
     auto planT = [&](Arena& A) {
         A.off = 0;
@@ -694,6 +701,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
         ff = A.f(bt * 2048);
         dcat = A.f(bt * 640);
         gxT = A.f(bt * 2048);
+        gxT2 = A.f(bt * 2048);  // LSTM input products of the TextEncoder branch (side stream)
         xl = A.f(bt * 512);
         logits = A.f(bt * 50);
         te0 = A.f(bt * 512);
@@ -716,6 +724,38 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
         return t;
     };
     launch_style_fc(fc_dev_, (int)fc_host_.size(), d_styles, gb_, gb_total_, B, stream_);
+
+    // --- TextEncoder (embedding, 3 x conv k5 + LayerNorm + LeakyReLU, biLSTM) ---
+    // Independent of the ALBERT / duration branch below: it runs on the side stream beside it (at small batch
+    // neither branch fills the chip: the recurrences use one CU per utterance and direction).
+    KX_HIP(hipEventRecord(ev_fork_, stream_));
+    KX_HIP(hipStreamWaitEvent(stream2_, ev_fork_, 0));
+    struct StreamSwap {  // every launch helper issues on stream_; put the side stream there for this block
+        hipStream_t &a, &b;
+        StreamSwap(hipStream_t& x, hipStream_t& y) : a(x), b(y) { std::swap(a, b); }
+        ~StreamSwap() { std::swap(a, b); }
+    };
+    T t_ten = TT(t_en, 512);
+    {
+    StreamSwap on_side(stream_, stream2_);
+    T t_te0 = TT(te0, 512), t_te1 = TT(te1, 512);
+    launch_embed(d_ids, t_stride, wt("text_encoder.embedding.weight"), 512, te0, t_te0.bs, Tp, dT_, B, Tmax, stream_);
+    T* cur = &t_te0;
+    T* nxt = &t_te1;
+    for (int i = 0; i < 3; ++i) {
+        ConvOpts o;
+        o.pad = 2;
+        conv(convs_.at("text_encoder.cnn." + std::to_string(i)), *cur, *nxt, o);
+        const std::string ln = "text_encoder.cnn." + std::to_string(i) + ".1.";
+        launch_layernorm_ch(nxt->p, nxt->p, nxt->bs, Tp, 512, LT, B, Tmax, 1e-5f, LN_AFFINE, wt(ln + "gamma"),
+                            wt(ln + "beta"), 0, 0.2f, stream_);
+        std::swap(cur, nxt);
+    }
+    tap("text_enc.cnn", *cur);
+    lstm(lstms_.at("text_encoder.lstm"), *cur, t_ten, gxT2);
+    tap("text_enc.out", t_ten);
+    KX_HIP(hipEventRecord(ev_join_, stream_));
+    }
 
     // --- PL-BERT (ALBERT, 12 passes over one shared layer) ---
     const std::string E = "bert.embeddings.";
@@ -770,25 +810,8 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
                     stream_);
     KX_HIP(hipMemcpyAsync(hF_.data(), dF_, B * sizeof(int), hipMemcpyDeviceToHost, stream_));
 
-    // --- TextEncoder (embedding, 3 x conv k5 + LayerNorm + LeakyReLU, biLSTM) ---
-    T t_te0 = TT(te0, 512), t_te1 = TT(te1, 512), t_ten = TT(t_en, 512);
-    launch_embed(d_ids, t_stride, wt("text_encoder.embedding.weight"), 512, te0, t_te0.bs, Tp, dT_, B, Tmax, stream_);
-    T* cur = &t_te0;
-    T* nxt = &t_te1;
-    for (int i = 0; i < 3; ++i) {
-        ConvOpts o;
-        o.pad = 2;
-        conv(convs_.at("text_encoder.cnn." + std::to_string(i)), *cur, *nxt, o);
-        const std::string ln = "text_encoder.cnn." + std::to_string(i) + ".1.";
-        launch_layernorm_ch(nxt->p, nxt->p, nxt->bs, Tp, 512, LT, B, Tmax, 1e-5f, LN_AFFINE, wt(ln + "gamma"),
-                            wt(ln + "beta"), 0, 0.2f, stream_);
-        std::swap(cur, nxt);
-    }
-    tap("text_enc.cnn", *cur);
-    lstm(lstms_.at("text_encoder.lstm"), *cur, t_ten, gxT);
-    tap("text_enc.out", t_ten);
-
     // ===== the one host round trip: predicted frame counts size everything downstream =========
+    KX_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));  // the TextEncoder branch joins here
     KX_HIP(hipStreamSynchronize(stream_));
     int Fmax = 0;
     for (int b = 0; b < B; ++b) Fmax = hF_[b] > Fmax ? hF_[b] : Fmax;
