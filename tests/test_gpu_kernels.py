@@ -151,3 +151,38 @@ def test_attention_matches_float64_softmax(T, lens):
         err = np.abs(got[b, :, :L] - ref[b, :, :L]).max()
         assert err < 2e-5, (b, L, err)
         assert np.all(got[b, :, L:] == 0.0)                     # columns past the utterance are not written
+
+
+def _sweep_cases(n, seed):
+    """Random conv shapes concentrated on tile borders: columns around multiples of 128 / 256, output channels
+    around the 32 / 64 / 128-row tiles, every kernel width and dilation the graph uses."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(n):
+        k = int(rng.choice([1, 2, 3, 5, 7, 11]))
+        d = int(rng.choice([1, 3, 5])) if k >= 3 else 1
+        base = int(rng.choice([128, 256, 384, 512, 768]))
+        L = max(1, base + int(rng.integers(-3, 4)))
+        Cout = max(1, int(rng.choice([32, 64, 128, 256])) + int(rng.integers(-5, 6)))
+        Cin = int(rng.choice([3, 16, 17, 48, 96, 130]))
+        B = int(rng.integers(1, 4))
+        pad = (k - 1) * d // 2
+        cases.append((B, Cin, Cout, L, k, pad, d))
+    return cases
+
+
+@pytest.mark.parametrize("B,Cin,Cout,L,k,p,d", _sweep_cases(36, seed=2024))
+def test_conv1d_tile_border_sweep(B, Cin, Cout, L, k, p, d):
+    """Both contraction modes must agree with float64 at every tile border (full / edge epilogue forms, the
+    128- and 256-column tiles, the small-grid 4x1 tiles, virtual taps for k = 1)."""
+    from kokorox_amd import hip_koko as hk
+    rng = np.random.default_rng(B * 7919 + Cin * 131 + Cout * 17 + L + k)
+    x = rng.standard_normal((B, Cin, L), dtype=np.float32)
+    w = (rng.standard_normal((Cout, Cin, k), dtype=np.float32) / np.sqrt(Cin * k)).astype(np.float32)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    ref = F.conv1d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                   padding=p, dilation=d).numpy()
+    for mode in (1, 0):
+        y = hk.conv1d(x, w, b, pad=p, dil=d, mode=mode)
+        assert y.shape == ref.shape
+        assert np.abs(y - ref).max() < 2e-5, (mode, np.abs(y - ref).max())
