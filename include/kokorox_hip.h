@@ -182,6 +182,14 @@ int kx_test_conv1d(int device_id, const float* x, int B, int Cin, int L, const f
                    int transposed, int act, float slope, const float* alpha,
                    const float* norm, float* y, int Lout, int mode, char* err, size_t err_len);
 
+/* The epilogue forms of the same kernel on a stride-1 conv: y = (conv + bias + resid [+ y]) * out_mul / out_div
+ * with y [B,Cout,Lout] (Lout = L + 2 pad - dil (k-1)) read as the running sum when accumulate != 0, and - when
+ * stats_out [B,Cout,2] is given - the fused InstanceNorm partial sums (sum, sum of squares of each stored row). */
+int kx_test_conv1d_epilogue(int device_id, const float* x, int B, int Cin, int L, const float* w,
+                            const float* bias, int Cout, int k, int pad, int dil, const float* resid,
+                            int accumulate, float out_mul, float out_div, float* y, float* stats_out,
+                            int mode, char* err, size_t err_len);
+
 /* Stand-alone bidirectional LSTM (hidden 256): x [B,L,n_in] -> y [B,L,512]. */
 int kx_test_lstm(int device_id, const float* x, int B, int L, int n_in, const float* w_ih,
                  const float* w_hh, const float* b_ih, const float* b_hh, const float* w_ih_r,

@@ -241,9 +241,19 @@ int kx_debug_tap(kx_model* m, const char* name, int b, float* out, int64_t out_c
 
 // ---- stand-alone kernel hooks for tests/ ------------------------------------------------------
 
-int kx_test_conv1d(int device_id, const float* x, int B, int Cin, int L, const float* w, const float* bias, int Cout,
-                   int k, int stride, int pad, int dil, int transposed, int act, float slope, const float* alpha,
-                   const float* norm, float* y, int Lout, int mode, char* err, size_t err_len) {
+namespace {
+struct ConvTestExtra {  // epilogue forms beyond bias: residual, accumulate into y, scale / divide, fused statistics
+    const float* resid = nullptr;
+    int accum = 0;
+    float out_mul = 1.f, out_div = 1.f;
+    float* stats_out = nullptr;  // [B][Cout][2] = sum, sum of squares over the stored row
+};
+}  // namespace
+
+static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L, const float* w, const float* bias, int Cout,
+                            int k, int stride, int pad, int dil, int transposed, int act, float slope, const float* alpha,
+                            const float* norm, float* y, int Lout, int mode, const ConvTestExtra& ex, char* err,
+                            size_t err_len) {
     return guarded_free(err, err_len, [&] {
         check_device(device_id);
         KX_REQUIRE(x && w && y && B > 0 && Cin > 0 && Cout > 0 && L > 0 && Lout > 0 && k > 0, "test_conv1d: bad argument");
@@ -304,12 +314,39 @@ int kx_test_conv1d(int device_id, const float* x, int B, int Cin, int L, const f
         a.alpha = alpha ? dm.up(alpha, (size_t)Cin) : nullptr;
         KX_REQUIRE(act != kx::ACT_SNAKE || alpha, "test_conv1d: snake needs alpha");
         float* dy = dm.get<float>((size_t)B * Cout * Lout);
-        KX_HIP(hipMemset(dy, 0, (size_t)B * Cout * Lout * 4));
+        if (ex.accum)
+            KX_HIP(hipMemcpy(dy, y, (size_t)B * Cout * Lout * 4, hipMemcpyHostToDevice));  // y holds the running sum
+        else
+            KX_HIP(hipMemset(dy, 0, (size_t)B * Cout * Lout * 4));
         a.y = dy;
         a.y_bs = (long)Cout * Lout;
         a.y_ld = Lout;
-        a.out_mul = 1.f;
-        a.out_div = 1.f;
+        a.out_mul = ex.out_mul;
+        a.out_div = ex.out_div;
+        a.accum = ex.accum;
+        if (ex.resid) {
+            KX_REQUIRE(!transposed, "test_conv1d: residual with the plain conv only");
+            a.resid = dm.up(ex.resid, (size_t)B * Cout * Lout);
+            a.r_bs = (long)Cout * Lout;
+            a.r_ld = Lout;
+        }
+        float2* d_part = nullptr;
+        int cols_per_tile = 0;
+        if (ex.stats_out) {
+            KX_REQUIRE(!transposed && !ex.accum, "test_conv1d: fused statistics come with plain, non-accumulating stores");
+            int bn, wn;
+            if (mode == kx::CONV_F16X3) {
+                kx::conv16_pick_tile(BM, Lout, B, rows, &bn, &wn);
+            } else {
+                bn = kx::conv_bn(BM);
+                wn = BM == 128 ? 2 : 4;
+            }
+            a.stat_tiles = ((Lout + bn - 1) / bn) * wn;
+            cols_per_tile = bn / wn;
+            d_part = dm.get<float2>((size_t)B * rows * a.stat_tiles);
+            KX_HIP(hipMemset(d_part, 0, (size_t)B * rows * a.stat_tiles * sizeof(float2)));
+            a.stat_part = d_part;
+        }
         if (mode == kx::CONV_F16X3) {
             const float amax = kx::device_absmax(dw, (long)Cout * Cin * k, nullptr);
             const int ws = kx::pick_weight_shift(amax);
@@ -330,7 +367,42 @@ int kx_test_conv1d(int device_id, const float* x, int B, int Cin, int L, const f
         }
         KX_HIP(hipDeviceSynchronize());
         KX_HIP(hipMemcpy(y, dy, (size_t)B * Cout * Lout * 4, hipMemcpyDeviceToHost));
+        if (ex.stats_out) {
+            std::vector<float2> part((size_t)B * rows * a.stat_tiles);
+            KX_HIP(hipMemcpy(part.data(), d_part, part.size() * sizeof(float2), hipMemcpyDeviceToHost));
+            const int used = (Lout + cols_per_tile - 1) / cols_per_tile;
+            for (size_t br = 0; br < (size_t)B * rows; ++br) {
+                double sm = 0.0, sq = 0.0;
+                for (int t = 0; t < used && t < a.stat_tiles; ++t) {
+                    sm += part[br * a.stat_tiles + t].x;
+                    sq += part[br * a.stat_tiles + t].y;
+                }
+                ex.stats_out[2 * br] = (float)sm;
+                ex.stats_out[2 * br + 1] = (float)sq;
+            }
+        }
     });
+}
+
+int kx_test_conv1d(int device_id, const float* x, int B, int Cin, int L, const float* w, const float* bias, int Cout,
+                   int k, int stride, int pad, int dil, int transposed, int act, float slope, const float* alpha,
+                   const float* norm, float* y, int Lout, int mode, char* err, size_t err_len) {
+    return test_conv1d_impl(device_id, x, B, Cin, L, w, bias, Cout, k, stride, pad, dil, transposed, act, slope, alpha, norm,
+                            y, Lout, mode, ConvTestExtra{}, err, err_len);
+}
+
+int kx_test_conv1d_epilogue(int device_id, const float* x, int B, int Cin, int L, const float* w, const float* bias,
+                            int Cout, int k, int pad, int dil, const float* resid, int accumulate, float out_mul,
+                            float out_div, float* y, float* stats_out, int mode, char* err, size_t err_len) {
+    ConvTestExtra ex;
+    ex.resid = resid;
+    ex.accum = accumulate;
+    ex.out_mul = out_mul;
+    ex.out_div = out_div;
+    ex.stats_out = stats_out;
+    const int Lout = L + 2 * pad - dil * (k - 1);
+    return test_conv1d_impl(device_id, x, B, Cin, L, w, bias, Cout, k, 1, pad, dil, 0, 0, 0.f, nullptr, nullptr, y, Lout, mode,
+                            ex, err, err_len);
 }
 
 int kx_test_lstm(int device_id, const float* x, int B, int L, int n_in, const float* w_ih, const float* w_hh,

@@ -97,6 +97,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_test_lstm": (i32, [i32, vp, i32, i32, i32] + [vp] * 9 + [cp, sz]),
         "kx_test_source": (i32, [i32, vp, i32, i32, vp, f32, u64, u64, i32, vp, cp, sz]),
         "kx_test_attention": (i32, [i32, vp, vp, i32, i32, vp, cp, sz]),
+        "kx_test_conv1d_epilogue": (i32, [i32, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, vp, i32, f32, f32, vp, vp,
+                                          i32, cp, sz]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = the ABI lost a symbol
@@ -113,7 +115,7 @@ ABI_SYMBOLS = [
     "kx_set_conv_mode", "kx_get_conv_mode",
     "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_set_voice_table", "kx_infer_voices",
     "kx_infer_packed", "kx_free_packed", "kx_dispatcher_create", "kx_dispatcher_submit",
-    "kx_dispatcher_stats", "kx_dispatcher_destroy", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test_attention",
+    "kx_dispatcher_stats", "kx_dispatcher_destroy", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test_attention", "kx_test_conv1d_epilogue",
 ]
 
 
@@ -401,6 +403,22 @@ def conv1d(x, w, bias=None, stride=1, pad=0, dil=1, transposed=False, act=0, slo
     _err_call(lib.kx_test_conv1d, device, _ptr(x), B, Cin, L, _ptr(w), _ptr(bias), Cout, k, stride, pad, dil,
               1 if transposed else 0, act, float(slope), _ptr(alpha), _ptr(norm), _ptr(y), Lout, mode)
     return y
+
+
+def conv1d_epilogue(x, w, bias=None, pad=0, dil=1, resid=None, y_init=None, out_mul=1.0, out_div=1.0, want_stats=False,
+                    mode=1, device=0):
+    """Stride-1 conv through the epilogue forms: y = (conv + bias + resid [+ y_init]) * out_mul / out_div, and the
+    fused per-row (sum, sum of squares) when want_stats.  Returns y or (y, stats[B,Cout,2])."""
+    lib = load_library()
+    x, w = _f32(x), _f32(w)
+    B, Cin, L = x.shape
+    Cout, _, k = w.shape
+    Lout = L + 2 * pad - dil * (k - 1)
+    y = np.zeros((B, Cout, Lout), dtype=np.float32) if y_init is None else _f32(y_init).copy()
+    st = np.zeros((B, Cout, 2), dtype=np.float32) if want_stats else None
+    _err_call(lib.kx_test_conv1d_epilogue, device, _ptr(x), B, Cin, L, _ptr(w), _ptr(_f32(bias)), Cout, k, pad, dil,
+              _ptr(_f32(resid)), 0 if y_init is None else 1, float(out_mul), float(out_div), _ptr(y), _ptr(st), mode)
+    return (y, st) if want_stats else y
 
 
 def lstm(x, params, device=0):

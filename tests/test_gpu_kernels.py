@@ -186,3 +186,45 @@ def test_conv1d_tile_border_sweep(B, Cin, Cout, L, k, p, d):
         y = hk.conv1d(x, w, b, pad=p, dil=d, mode=mode)
         assert y.shape == ref.shape
         assert np.abs(y - ref).max() < 2e-5, (mode, np.abs(y - ref).max())
+
+
+EPI_CASES = [
+    # B, Cin, Cout, L, k, pad, dil
+    (2, 48, 128, 700, 7, 3, 1),     # whole 128-row tile, full + edge column tiles (256-wide)
+    (1, 32, 130, 300, 3, 1, 1),     # ragged rows: second row tile has 2 rows
+    (3, 16, 64, 129, 5, 6, 3),      # BM = 64 tile, dilation
+    (2, 128, 128, 1025, 11, 25, 5), # generator shape, 5 column tiles
+    (1, 20, 22, 513, 7, 3, 1),      # BM = 32 tile (conv_post rows)
+]
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("B,Cin,Cout,L,k,p,d", EPI_CASES)
+def test_conv1d_epilogue_forms(B, Cin, Cout, L, k, p, d, mode):
+    """Residual, residual + accumulate + divide (the AdaINResBlock1 tail: mean over the three kernels), output scale,
+    and the fused InstanceNorm partial sums, each against float64."""
+    from kokorox_amd import hip_koko as hk
+    rng = np.random.default_rng(Cout * 31 + L)
+    x = rng.standard_normal((B, Cin, L), dtype=np.float32)
+    w = (rng.standard_normal((Cout, Cin, k), dtype=np.float32) / np.sqrt(Cin * k)).astype(np.float32)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    conv = F.conv1d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                    padding=p, dilation=d).numpy()
+    Lout = conv.shape[2]
+    res = rng.standard_normal((B, Cout, Lout), dtype=np.float32)
+    run = rng.standard_normal((B, Cout, Lout), dtype=np.float32)
+    # (1) residual + fused statistics
+    y, st = hk.conv1d_epilogue(x, w, b, pad=p, dil=d, resid=res, want_stats=True, mode=mode)
+    ref = conv + res.astype(np.float64)
+    assert np.abs(y - ref).max() < 2e-5
+    y64 = y.astype(np.float64)
+    assert np.abs(st[..., 0] - y64.sum(axis=2)).max() < 2e-3 * max(1.0, np.sqrt(Lout) / 10)
+    assert np.abs(st[..., 1] - (y64 * y64).sum(axis=2)).max() < 1e-5 * (y64 * y64).sum(axis=2).max()
+    # (2) residual + accumulate into a running sum, then the mean over 3
+    y2 = hk.conv1d_epilogue(x, w, b, pad=p, dil=d, resid=res, y_init=run, out_div=3.0, mode=mode)
+    ref2 = (conv + res.astype(np.float64) + run.astype(np.float64)) / 3.0
+    assert np.abs(y2 - ref2).max() < 2e-5
+    # (3) plain store with an output scale (the 1 / sqrt(2) of AdainResBlk1d) + statistics
+    y3, st3 = hk.conv1d_epilogue(x, w, b, pad=p, dil=d, out_mul=float(np.float32(0.70710678)), want_stats=True, mode=mode)
+    assert np.abs(y3 - conv * float(np.float32(0.70710678))).max() < 2e-5
+    assert np.abs(st3[..., 0] - y3.astype(np.float64).sum(axis=2)).max() < 2e-3 * max(1.0, np.sqrt(Lout) / 10)
