@@ -270,9 +270,12 @@ void launch_style_fc(const FcDesc* d_desc, int n_desc, const float* styles, floa
 }
 
 // ---- instance-norm statistics (f64 accumulation) ------------------------------------------
+// raw_out (optional): [B][C][2] float2 = the row's (sum, sum of squares) as a high and a low float part, i.e. two
+// "tiles" that stats_finalize_kernel adds back up in f64: later AdaINs of the SAME tensor (the three resblocks of a
+// generator stage all normalise the stage input) then skip the pass over the data.
 __global__ __launch_bounds__(256) void in_stats_kernel(const float* x, long bs, int ld, LenMap len, const float* gb,
                                                        long gb_bs, int C, float* mean, float* scale, float* shift,
-                                                       int n_bs) {
+                                                       int n_bs, float2* raw_out) {
     __shared__ double rs[4], rq[4];
     const int c = blockIdx.x, b = blockIdx.y;
     const int L = len_of(len, b);
@@ -295,6 +298,11 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const float* x, long bs, 
     __syncthreads();
     if (threadIdx.x == 0) {
         const double S = (rs[0] + rs[1]) + (rs[2] + rs[3]), Q = (rq[0] + rq[1]) + (rq[2] + rq[3]);
+        if (raw_out) {
+            const float sh = (float)S, qh = (float)Q;
+            raw_out[((long)b * C + c) * 2 + 0] = make_float2(sh, qh);
+            raw_out[((long)b * C + c) * 2 + 1] = make_float2((float)(S - (double)sh), (float)(Q - (double)qh));
+        }
         const double m = L > 0 ? S / L : 0.0;
         double var = L > 0 ? Q / L - m * m : 0.0;
         if (var < 0.0) var = 0.0;
@@ -306,9 +314,9 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const float* x, long bs, 
     }
 }
 void launch_in_stats(const float* x, long bs, int ld, int C, LenMap len, int B, const float* gb, long gb_bs,
-                     float* mean, float* scale, float* shift, int n_bs, hipStream_t s) {
+                     float* mean, float* scale, float* shift, int n_bs, float2* raw_out, hipStream_t s) {
     hipLaunchKernelGGL(in_stats_kernel, dim3(C, B), dim3(256), 0, s, x, bs, ld, len, gb, gb_bs, C, mean, scale,
-                       shift, n_bs);
+                       shift, n_bs, raw_out);
     KX_HIP(hipGetLastError());
 }
 

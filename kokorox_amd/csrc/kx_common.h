@@ -154,7 +154,7 @@ void launch_style_fc(const FcDesc* d_desc, int n_desc, const float* styles, floa
 void launch_stats_finalize(const float2* part, int tiles, int cols_per_tile, int C, LenMap len, int B, const float* gb,
                            long gb_bs, float* mean, float* scale, float* shift, int n_bs, hipStream_t s);
 void launch_in_stats(const float* x, long bs, int ld, int C, LenMap len, int B, const float* gb, long gb_bs,
-                     float* mean, float* scale, float* shift, int n_bs, hipStream_t s);
+                     float* mean, float* scale, float* shift, int n_bs, float2* raw_out, hipStream_t s);
 
 void launch_style_mix(const float* table, int n_voices, const int* voice_ids, const float* weights, int max_mix,
                       const int* rows, float* styles, int B, hipStream_t s);

@@ -170,6 +170,7 @@ class Model {
     float* d_voices_ = nullptr;  // [n_voices_][511][256]
     int n_voices_ = 0;
     int* d_pinned_ = nullptr;
+    Arena* stats_arena_ = nullptr;  // where stats() keeps the raw sums of tensors it had to read (frame-axis arena)
     int n_pinned_ = 0;
 
     // per-call state

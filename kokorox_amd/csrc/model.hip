@@ -471,6 +471,8 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
 }
 
 void Model::stats(const T& x, const std::string& fc_key) {
+    // a tensor whose sums are not known yet gets a small cache for them (planned in the dry run like everything else)
+    float2* raw = stats_arena_ ? reinterpret_cast<float2*>(stats_arena_->alloc((size_t)B_ * x.C * 2 * sizeof(float2))) : nullptr;
     if (dry_) return;
     auto it = parts_.find(x.p);
     if (it != parts_.end() && it->second.C == x.C) {
@@ -480,7 +482,9 @@ void Model::stats(const T& x, const std::string& fc_key) {
         return;
     }
     launch_in_stats(x.p, x.bs, x.ld, x.C, x.len, B_, gb_ + fc_off(fc_key), gb_total_, nmean_, nscale_, nshift_, n_bs_,
-                    stream_);
+                    raw, stream_);
+    // (two "tiles" of one column each: the high and the low part of the f64 sums)
+    if (raw) parts_[x.p] = PartInfo{raw, 2, 1, x.C};
 }
 
 void Model::tap(const char* name, const T& t) {
@@ -832,6 +836,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     };
     auto back = [&](Arena& A) {
         A.off = 0;
+        stats_arena_ = &A;
         auto F1 = [&](int C) { return mk(A, C, F1p, LF1, Fmax); };
         auto F2 = [&](int C) { return mk(A, C, F2p, LF2, 2 * Fmax); };
         auto F20 = [&](int C) { return mk(A, C, F20p, LF20, 20 * Fmax); };
