@@ -12,7 +12,7 @@ def main(prof_dir, bench_json, out):
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     lines = [f"# rocprofv3 --kernel-trace --stats summary ({os.path.basename(prof_dir)})",
              "# command: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py "
-             "--steps 3 --warmup 1 --cpu-utts 0 --free-run 0",
+             "--steps 3 --warmup 1 --cpu-utts 0 --free-run 0 --pcie 0",
              f"# total GPU kernel time {tot / 1e6:.2f} ms", "",
              f"{'kernel':88s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>7s}"]
     for r in rows:
