@@ -57,17 +57,30 @@ kx_model* kx_create(const char* weights_path, int device_id, char* err, size_t e
 kx_model* kx_create_from_device_blob(const void* d_blob, size_t n_bytes, int device_id,
                                      char* err, size_t err_len);
 
+/* One model per GPU for the server (the reference's server is ONE process, kokorox-openai/src/lib.rs:
+ * 370-439): reads the weight file ONCE, uploads it to device_ids[0] over PCIe and fans it out to the other
+ * devices with concurrent device-to-device copies (hipMemcpyPeerAsync, one xGMI link per destination), then builds
+ * every model from its resident blob.  out_models[n] receives the handles, ready for kx_dispatcher_create; ids may
+ * repeat (several models on one GPU).  On failure nothing is leaked and every entry of out_models is NULL.
+ * (A multi-PROCESS launch — one rank per GPU, as bench.py under torch.distributed — uses an RCCL broadcast of the
+ * blob and kx_create_from_device_blob instead: kokorox_amd/dist.py.) */
+int kx_create_replicas(const char* weights_path, const int* device_ids, int n, kx_model** out_models, char* err,
+                       size_t err_len);
+
 /* Replaces `Drop for OrtKoko` / TTSKoko::cleanup (kokorox/src/tts/koko.rs:1338-1375). */
 void kx_destroy(kx_model* m);
 
-/* Text of the last failure on this model ("" if none).  Valid until the next call. */
+/* Text of the last failure on this model ("" if none).  The returned pointer refers to a copy owned by the
+ * calling thread: it stays valid until that thread calls kx_last_error again, whatever other threads do with
+ * the model.  kx_last_error_copy writes the same text into a caller buffer (always NUL-terminated). */
 const char* kx_last_error(const kx_model* m);
+int kx_last_error_copy(const kx_model* m, char* buf, size_t buf_len);
 
 /* Replaces `OrtKoko::infer(tokens, styles, speed)` (kokorox/src/onn/ort_koko.rs:37-91;
  * caller kokorox/src/tts/koko.rs:1177).
  *   ids      [B, t_stride] int64, row b holds lens[b] token ids already wrapped with the
  *            0 pad at both ends (koko.rs:1169-1173); ids must be in 0..177 (vocab.rs:5-20)
- *   lens     [B] tokens per utterance incl. the two pads, 3..512.  The reference is
+ *   lens     [B] tokens per utterance incl. the two pads, 1..512 (3..512 for real text).  The reference is
  *            batch-1 (koko.rs:1175); B>1 gives the same result as B separate calls.
  *   styles   [B,256] float32 voice-style rows (mix_styles, koko.rs:1255-1306)
  *   speeds   [n_speed] float32, n_speed = 1 (shared, ort_koko.rs:67-68) or B
@@ -90,7 +103,9 @@ void kx_free_audio(float* p);
  *   d_audio      [B, audio_ld] float32, written for samples < 600*frames[b]
  *   d_frames     [B] int32 predicted frame counts
  * Returns KX_ERR_INVALID if audio_ld is smaller than the longest waveform (the needed
- * length is then in *need_ld).  The call returns after the work has been queued on the
+ * length is then in *need_ld), or if a token id in d_ids lies outside 0..177: device-side ids are range-checked by
+ * the embedding kernels (clamped for the gather, so nothing is read out of bounds) and reported at the call's one
+ * host synchronisation point.  The call returns after the work has been queued on the
  * model's stream and its frame counts are known; kx_sync waits for completion. */
 int kx_infer_device(kx_model* m, const int64_t* d_ids, int64_t t_stride, const int32_t* lens_host,
                     int B, const float* d_styles, const float* speeds_host, int n_speed,
@@ -109,6 +124,18 @@ int kx_set_pinned_durations(kx_model* m, const int32_t* pattern, int n);
  * significant bits per product, f32 accumulation).  Default 1; env KOKOROX_CONV=f32 selects 0 at create. */
 int kx_set_conv_mode(kx_model* m, int mode);
 int kx_get_conv_mode(kx_model* m);
+
+/* Which STFT / inverse-STFT pair the generator uses (n_fft 20, hop 5 on both):
+ *   0 = the conv-based pair of the ONNX export (upstream custom_stft.py: magnitude sqrt(re^2+im^2+1e-14), phase
+ *       atan2 with (im == 0 && re < 0) -> +pi, inverse = cos/sin * window / n_fft transposed convolutions summed as
+ *       real - imag, without one-sided doubling or window-envelope division).  Default: `model.onnx` is what the
+ *       reference runs (kokorox/src/utils/hf_cache.rs:8-10, ort_koko.rs:79).
+ *   1 = torch.stft / torch.istft semantics (the PyTorch checkpoint's own path).
+ * Both are restated from the public upstream sources from memory: which of the two the
+ * shipped graph contains is the first thing to confirm when a real model.onnx is reachable.  Env KOKOROX_STFT=torch
+ * selects 1 at create. */
+int kx_set_stft_variant(kx_model* m, int variant);
+int kx_get_stft_variant(kx_model* m);
 
 /* First utterance index used for the noise stream of the next calls (default 0). */
 int kx_set_utterance_base(kx_model* m, uint64_t utt_base);
@@ -176,7 +203,8 @@ int kx_debug_tap(kx_model* m, const char* name, int b, float* out, int64_t out_c
 /* Stand-alone run of the conv1d MFMA kernel on host arrays (x [B,Cin,L], w [Cout,Cin,k]
  * or, for transposed = 1, [Cin,Cout,k]); y must hold B*Cout*Lout floats.  act: 0 none,
  * 1 leaky(slope), 2 snake(alpha[Cin]); norm = optional [3,B,Cin] (mean, scale, shift);
- * mode as in kx_set_conv_mode. */
+ * mode as in kx_set_conv_mode, plus 2 = f16x3 through the opt-in wave-specialised persistent kernel
+ * (conv_f16x3_ws.hip; shapes it does not cover take the default f16x3 kernel). */
 int kx_test_conv1d(int device_id, const float* x, int B, int Cin, int L, const float* w,
                    const float* bias, int Cout, int k, int stride, int pad, int dil,
                    int transposed, int act, float slope, const float* alpha,

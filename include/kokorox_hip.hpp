@@ -19,6 +19,19 @@ class HipKoko {
         h_ = kx_create(model_path.c_str(), device, err, sizeof(err));
         if (!h_) throw std::runtime_error(std::string("Failed to create Kokoro TTS model: ") + err);
     }
+    // One model per device id from one read of the weight file (kx_create_replicas): what a single-process server
+    // hands to kx_dispatcher_create (the reference holds one Arc<OrtKoko>, kokorox-openai/src/lib.rs:370-439).
+    static std::vector<HipKoko> replicas(const std::string& model_path, const std::vector<int>& devices) {
+        std::vector<kx_model*> hs(devices.size(), nullptr);
+        char err[512] = {0};
+        if (kx_create_replicas(model_path.c_str(), devices.data(), (int)devices.size(), hs.data(), err, sizeof(err)) != KX_OK)
+            throw std::runtime_error(std::string("Failed to create Kokoro TTS model: ") + err);
+        std::vector<HipKoko> out;
+        out.reserve(hs.size());
+        for (kx_model* h : hs) out.push_back(HipKoko(h));
+        return out;
+    }
+    kx_model* handle() const { return h_; }
     HipKoko(const HipKoko&) = delete;
     HipKoko& operator=(const HipKoko&) = delete;
     HipKoko(HipKoko&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
@@ -47,7 +60,11 @@ class HipKoko {
         std::vector<int64_t> ol(B);
         const int rc = kx_infer(h_, ids.data(), (int64_t)stride, tl.data(), B, st.data(), &speed, 1, seed, 0, &out,
                                 ol.data());
-        if (rc != KX_OK) throw std::runtime_error(std::string("kokorox_hip error: ") + kx_last_error(h_));
+        if (rc != KX_OK) {
+            char msg[512];
+            kx_last_error_copy(h_, msg, sizeof(msg));  // (a copy of our own: other threads may fail on this model meanwhile)
+            throw std::runtime_error(std::string("kokorox_hip error: ") + msg);
+        }
         int64_t total = 0;
         for (int64_t v : ol) total += v;
         std::vector<float> wav(out, out + total);  // the same owned copy as ort_koko.rs:85
@@ -57,6 +74,7 @@ class HipKoko {
     }
 
   private:
+    explicit HipKoko(kx_model* adopted) : h_(adopted) {}
     kx_model* h_ = nullptr;
 };
 

@@ -119,6 +119,72 @@ kx_model* kx_create_from_device_blob(const void* d_blob, size_t n_bytes, int dev
     return rc == KX_OK ? h : nullptr;
 }
 
+int kx_create_replicas(const char* weights_path, const int* device_ids, int n, kx_model** out_models, char* err,
+                       size_t err_len) {
+    if (out_models)
+        for (int i = 0; i < n; ++i) out_models[i] = nullptr;
+    std::vector<void*> blobs;       // per replica: its device blob until a model has adopted it
+    std::vector<int> blob_dev;
+    std::vector<hipStream_t> streams;
+    std::vector<kx_model*> made;
+    int rc = guarded_free(err, err_len, [&] {
+        KX_REQUIRE(device_ids && out_models && n >= 1 && n <= 64, "create_replicas: 1..64 device ids and an output array");
+        for (int i = 0; i < n; ++i) check_device(device_ids[i]);
+        const std::vector<unsigned char> host = kx::read_weight_file(weights_path);  // the ONE file read
+        const size_t nb = host.size();
+        blobs.assign(n, nullptr);
+        blob_dev.assign(device_ids, device_ids + n);
+        streams.assign(n, nullptr);
+        // replica 0: host -> device over PCIe, once
+        KX_HIP(hipSetDevice(device_ids[0]));
+        KX_HIP(hipMalloc(&blobs[0], nb));
+        KX_HIP(hipMemcpy(blobs[0], host.data(), nb, hipMemcpyHostToDevice));
+        // every other replica: device -> device from replica 0, all copies in flight together (xGMI is
+        // point-to-point: each destination has its own link to the source, so they do not share bandwidth)
+        for (int i = 1; i < n; ++i) {
+            KX_HIP(hipSetDevice(device_ids[i]));
+            if (device_ids[i] != device_ids[0]) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[0]) == hipSuccess && can) {
+                    hipError_t pe = hipDeviceEnablePeerAccess(device_ids[0], 0);
+                    if (pe != hipSuccess) (void)hipGetLastError();  // already enabled, or staged copies: both fine
+                }
+            }
+            KX_HIP(hipMalloc(&blobs[i], nb));
+            KX_HIP(hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking));
+            KX_HIP(hipMemcpyPeerAsync(blobs[i], device_ids[i], blobs[0], device_ids[0], nb, streams[i]));
+        }
+        for (int i = 1; i < n; ++i) {
+            KX_HIP(hipSetDevice(device_ids[i]));
+            KX_HIP(hipStreamSynchronize(streams[i]));
+        }
+        for (int i = 0; i < n; ++i) {
+            std::unique_ptr<Model> m(new Model(device_ids[i]));
+            void* b = blobs[i];
+            blobs[i] = nullptr;  // the model owns it from here on (freed by its destructor, also on a failed build)
+            m->adopt_blob_guard(b);
+            m->load_device_blob(b, nb, /*adopt=*/true);
+            made.push_back(new kx_model{std::move(m)});
+        }
+    });
+    for (size_t i = 0; i < streams.size(); ++i)
+        if (streams[i]) {
+            (void)hipSetDevice(blob_dev[i]);
+            (void)hipStreamDestroy(streams[i]);
+        }
+    for (size_t i = 0; i < blobs.size(); ++i)
+        if (blobs[i]) {
+            (void)hipSetDevice(blob_dev[i]);
+            (void)hipFree(blobs[i]);
+        }
+    if (rc != KX_OK) {
+        for (kx_model* h : made) kx_destroy(h);
+        return rc;
+    }
+    for (int i = 0; i < n; ++i) out_models[i] = made[i];
+    return KX_OK;
+}
+
 void kx_destroy(kx_model* m) {
     if (!m) return;
     try {
@@ -127,15 +193,43 @@ void kx_destroy(kx_model* m) {
     }
 }
 
-const char* kx_last_error(const kx_model* m) { return (m && m->m) ? m->m->last_error.c_str() : "null model"; }
+// The message is copied under the model's mutex into storage owned by the CALLING thread: another thread failing on
+// the same model afterwards cannot change or free what this pointer refers to.
+const char* kx_last_error(const kx_model* m) {
+    static thread_local std::string tls;
+    if (!m || !m->m) return "null model";
+    try {
+        std::lock_guard<std::mutex> lk(m->m->mu);
+        tls = m->m->last_error;
+    } catch (...) {
+        return "unknown failure";
+    }
+    return tls.c_str();
+}
+
+int kx_last_error_copy(const kx_model* m, char* buf, size_t buf_len) {
+    if (!buf || !buf_len) return KX_ERR_INVALID;
+    if (!m || !m->m) {
+        set_err(buf, buf_len, "null model");
+        return KX_ERR_INVALID;
+    }
+    try {
+        std::lock_guard<std::mutex> lk(m->m->mu);
+        set_err(buf, buf_len, m->m->last_error);
+    } catch (...) {
+        set_err(buf, buf_len, "unknown failure");
+        return KX_ERR_DEVICE;
+    }
+    return KX_OK;
+}
 
 int kx_infer(kx_model* m, const int64_t* ids, int64_t t_stride, const int32_t* lens, int B, const float* styles,
              const float* speeds, int n_speed, uint64_t seed, uint32_t flags, float** out, int64_t* out_lens) {
     return guarded(m, [&](Model& M) { M.infer_host(ids, t_stride, lens, B, styles, speeds, n_speed, seed, flags, out, out_lens); });
 }
 
-void kx_free_audio(float* p) { free(p); }
-void kx_free_packed(void* p) { free(p); }
+void kx_free_audio(float* p) { kx::host_out_free(p); }
+void kx_free_packed(void* p) { kx::host_out_free(p); }
 
 int kx_set_voice_table(kx_model* m, const float* table, int n_voices) {
     return guarded(m, [&](Model& M) { M.set_voice_table(table, n_voices); });
@@ -193,6 +287,17 @@ int kx_set_conv_mode(kx_model* m, int mode) {
 }
 
 int kx_get_conv_mode(kx_model* m) { return (m && m->m) ? m->m->conv_mode : -1; }
+
+int kx_set_stft_variant(kx_model* m, int variant) {
+    return guarded(m, [&](Model& M) {
+        KX_REQUIRE(variant == kx::STFT_ONNX || variant == kx::STFT_TORCH,
+                   "stft variant must be 0 (ONNX export: conv-based pair) or 1 (torch.stft / torch.istft)");
+        M.sync();
+        M.stft_variant = variant;
+    });
+}
+
+int kx_get_stft_variant(kx_model* m) { return (m && m->m) ? m->m->stft_variant : -1; }
 
 int kx_set_utterance_base(kx_model* m, uint64_t utt_base) {
     return guarded(m, [&](Model& M) { M.utt_base = utt_base; });
@@ -260,7 +365,9 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
         KX_HIP(hipSetDevice(device_id));
         DevMem dm;
         std::vector<int> lens(B, 1);
+        KX_REQUIRE(mode >= kx::CONV_F32 && mode <= kx::CONV_F16X3_WS, "test_conv1d: mode must be 0, 1 or 2");
         kx::ConvArgs a{};
+        a.ws_force = mode == kx::CONV_F16X3_WS ? 1 : 0;
         a.x = dm.up(x, (size_t)B * Cin * L);
         a.x_bs = (long)Cin * L;
         a.x_ld = L;
@@ -335,8 +442,8 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
         if (ex.stats_out) {
             KX_REQUIRE(!transposed && !ex.accum, "test_conv1d: fused statistics come with plain, non-accumulating stores");
             int bn, wn;
-            if (mode == kx::CONV_F16X3) {
-                kx::conv16_pick_tile(BM, Lout, B, rows, &bn, &wn);
+            if (mode != kx::CONV_F32) {
+                kx::conv16_pick_tile(BM, Lout, B, rows, a.K, a.dil, a.stride, &bn, &wn, a.ws_force);
             } else {
                 bn = kx::conv_bn(BM);
                 wn = BM == 128 ? 2 : 4;
@@ -347,7 +454,7 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
             KX_HIP(hipMemset(d_part, 0, (size_t)B * rows * a.stat_tiles * sizeof(float2)));
             a.stat_part = d_part;
         }
-        if (mode == kx::CONV_F16X3) {
+        if (mode != kx::CONV_F32) {
             const float amax = kx::device_absmax(dw, (long)Cout * Cin * k, nullptr);
             const int ws = kx::pick_weight_shift(amax);
             const int Kp = transposed ? 2 : k;

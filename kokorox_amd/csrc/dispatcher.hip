@@ -121,7 +121,7 @@ struct kx_dispatcher {
                 off += out_lens[b];
             }
         }
-        free(out);
+        kx::host_out_free(out);  // (the batch buffer is one of the pooled page-locked ones)
     }
 };
 

@@ -36,31 +36,43 @@ void launch_transpose_whh(const float* whh, float* out, hipStream_t s) {
 
 // ---- embeddings -------------------------------------------------------------------------
 // ALBERT: word[id] + token_type[0] + position[t]  (channel-major out [B][128][ld])
+// Token ids come straight from the caller's device buffer on the serving entry point (kx_infer_device): an id
+// outside the table must not become an out-of-bounds read.  It is clamped for the gather and recorded in a sticky
+// device word (first offender: (b << 16 | t) + 1) that the host reads at the forward's one synchronisation point
+// and turns into KX_ERR_INVALID.
+__device__ __forceinline__ long checked_id(long id, int n_vocab, int b, int t, unsigned* bad) {
+    if (id >= 0 && id < n_vocab) return id;
+    if (bad) atomicCAS(bad, 0u, (((unsigned)b << 16) | (unsigned)t) + 1u);
+    return id < 0 ? 0 : n_vocab - 1;
+}
+
 __global__ void albert_embed_kernel(const int64_t* ids, long ids_stride, const float* word, const float* type0,
-                                    const float* pos, float* out, long bs, int ld, const int* lens) {
+                                    const float* pos, float* out, long bs, int ld, const int* lens, int n_vocab,
+                                    unsigned* bad) {
     const int t = blockIdx.x, b = blockIdx.y, e = threadIdx.x;
     if (t >= lens[b]) return;
-    const long id = ids[b * ids_stride + t];
+    const long id = checked_id(ids[b * ids_stride + t], n_vocab, b, t, e == 0 ? bad : nullptr);
     out[b * bs + (long)e * ld + t] = (word[id * 128 + e] + type0[e]) + pos[t * 128 + e];
 }
 void launch_albert_embed(const int64_t* ids, long ids_stride, const float* word, const float* type0,
                          const float* pos, float* out, long bs, int ld, const int* lens, int B, int Tmax,
-                         hipStream_t s) {
+                         int n_vocab, unsigned* bad_id, hipStream_t s) {
     hipLaunchKernelGGL(albert_embed_kernel, dim3(Tmax, B), dim3(128), 0, s, ids, ids_stride, word, type0, pos,
-                       out, bs, ld, lens);
+                       out, bs, ld, lens, n_vocab, bad_id);
     KX_HIP(hipGetLastError());
 }
 
 __global__ void embed_kernel(const int64_t* ids, long ids_stride, const float* table, int C, float* out, long bs,
-                             int ld, const int* lens) {
+                             int ld, const int* lens, int n_vocab, unsigned* bad) {
     const int t = blockIdx.x, b = blockIdx.y;
     if (t >= lens[b]) return;
-    const long id = ids[b * ids_stride + t];
+    const long id = checked_id(ids[b * ids_stride + t], n_vocab, b, t, threadIdx.x == 0 ? bad : nullptr);
     for (int c = threadIdx.x; c < C; c += blockDim.x) out[b * bs + (long)c * ld + t] = table[id * C + c];
 }
 void launch_embed(const int64_t* ids, long ids_stride, const float* table, int C, float* out, long bs, int ld,
-                  const int* lens, int B, int Tmax, hipStream_t s) {
-    hipLaunchKernelGGL(embed_kernel, dim3(Tmax, B), dim3(256), 0, s, ids, ids_stride, table, C, out, bs, ld, lens);
+                  const int* lens, int B, int Tmax, int n_vocab, unsigned* bad_id, hipStream_t s) {
+    hipLaunchKernelGGL(embed_kernel, dim3(Tmax, B), dim3(256), 0, s, ids, ids_stride, table, C, out, bs, ld, lens,
+                       n_vocab, bad_id);
     KX_HIP(hipGetLastError());
 }
 
@@ -391,12 +403,13 @@ void launch_style_mix(const float* table, int n_voices, const int* voice_ids, co
 // f32 stereo = every sample written twice (koko.rs:1239-1246); PCM16 = (s.clamp(-1,1) * 32767) as i16,
 // i.e. truncation toward zero, NaN -> 0 (kokorox-websocket/src/lib.rs:701-704).
 __global__ void pack_audio_kernel(const float* audio, long audio_ld, const int* frames, int format, void* out,
-                                  long out_stride_bytes) {
+                                  long out_stride_bytes, const long* out_off) {
     const long j = blockIdx.x * (long)blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (j >= 600L * frames[b]) return;
     const float sv = audio[b * audio_ld + j];
-    char* ob = static_cast<char*>(out) + b * out_stride_bytes;
+    // out_off: byte offset of utterance b in a compact output (utterances back to back); else a fixed stride
+    char* ob = static_cast<char*>(out) + (out_off ? out_off[b] : b * out_stride_bytes);
     if (format == 1) {
         reinterpret_cast<float2*>(ob)[j] = make_float2(sv, sv);
     } else if (format == 2) {
@@ -407,9 +420,9 @@ __global__ void pack_audio_kernel(const float* audio, long audio_ld, const int* 
     }
 }
 void launch_pack_audio(const float* audio, long audio_ld, const int* frames, int B, int Fmax, int format, void* out,
-                       long out_stride_bytes, hipStream_t s) {
+                       long out_stride_bytes, const long* out_off, hipStream_t s) {
     hipLaunchKernelGGL(pack_audio_kernel, dim3((600 * Fmax + 255) / 256, B), dim3(256), 0, s, audio, audio_ld, frames,
-                       format, out, out_stride_bytes);
+                       format, out, out_stride_bytes, out_off);
     KX_HIP(hipGetLastError());
 }
 
@@ -718,10 +731,18 @@ void launch_source(const float* f0, long f0_bs, const int* frames, int B, int Fm
 }
 
 // ---- STFT (n_fft 20, hop 5, periodic Hann, replicate centre padding) and iSTFT head -------
+// Two variants of the pair, selected per model (kx_set_stft_variant):
+//   0 "onnx"  : the conv-based pair the ONNX export uses (upstream custom_stft.py, as recalled - SURVEY Appendix A):
+//               magnitude sqrt(re^2 + im^2 + 1e-14); phase atan2 with (im == 0 && re < 0) forced to +pi; inverse =
+//               two transposed convolutions with cos/sin * window / n_fft summed as real - imag: NO doubling of the
+//               interior one-sided bins and NO division by the window envelope.  This is the graph `sess.run`
+//               executes (kokorox/src/onn/ort_koko.rs:79), hence the default.
+//   1 "torch" : torch.stft / torch.istft semantics (one-sided irfft with doubled interior bins, overlap-add
+//               divided by the summed squared window) - what the PyTorch model does with disable_complex=False.
 __constant__ float c_fwd_re[11][20];
 __constant__ float c_fwd_im[11][20];
-__constant__ float c_inv_re[20][11];
-__constant__ float c_inv_im[20][11];
+__constant__ float c_inv_re[2][20][11];
+__constant__ float c_inv_im[2][20][11];
 __constant__ float c_win_sq[20];
 
 void init_dft_tables() {
@@ -733,15 +754,19 @@ void init_dft_tables() {
     }
     c[0] = 1; c[5] = 0; c[10] = -1; c[15] = 0;
     sn[0] = 0; sn[5] = 1; sn[10] = 0; sn[15] = -1;
-    float fr[11][20], fi[11][20], ir[20][11], ii[20][11], wsq[20];
+    float fr[11][20], fi[11][20], ir[2][20][11], ii[2][20][11], wsq[20];
     for (int k = 0; k < 11; ++k)
         for (int n = 0; n < 20; ++n) {
             const int m = (k * n) % 20;
             fr[k][n] = (float)(win[n] * c[m]);
             fi[k][n] = (float)(win[n] * (-sn[m]));
+            // variant 0: cos / sin * window / n_fft for every bin, combined as real - imag
+            ir[0][n][k] = (float)(c[m] / 20.0 * win[n]);
+            ii[0][n][k] = (float)(-sn[m] / 20.0 * win[n]);
+            // variant 1: one-sided irfft (interior bins doubled, imaginary parts of bins 0 and 10 ignored)
             const double ck = (k == 0 || k == 10) ? 1.0 : 2.0;
-            ir[n][k] = (float)((ck * c[m]) / 20.0 * win[n]);
-            ii[n][k] = (k == 0 || k == 10) ? 0.f : (float)((-ck * sn[m]) / 20.0 * win[n]);
+            ir[1][n][k] = (float)((ck * c[m]) / 20.0 * win[n]);
+            ii[1][n][k] = (k == 0 || k == 10) ? 0.f : (float)((-ck * sn[m]) / 20.0 * win[n]);
         }
     for (int n = 0; n < 20; ++n) wsq[n] = (float)(win[n] * win[n]);
     KX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_fwd_re), fr, sizeof(fr)));
@@ -751,7 +776,7 @@ void init_dft_tables() {
     KX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_win_sq), wsq, sizeof(wsq)));
 }
 
-__global__ void stft_kernel(const float* hs, long hs_bs, float* har, long bs, int ld, const int* frames) {
+__global__ void stft_kernel(const float* hs, long hs_bs, float* har, long bs, int ld, const int* frames, int variant) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     const int L = 600 * frames[b], nf = 120 * frames[b] + 1;
     if (f >= nf) return;
@@ -770,18 +795,26 @@ __global__ void stft_kernel(const float* hs, long hs_bs, float* har, long bs, in
             re += x[n] * c_fwd_re[k][n];
             im += x[n] * c_fwd_im[k][n];
         }
-        har[b * bs + (long)k * ld + f] = sqrtf(re * re + im * im);
-        har[b * bs + (long)(11 + k) * ld + f] = atan2f(im, re);
+        float mag, ph;
+        if (variant == 0) {
+            mag = sqrtf(re * re + im * im + 1e-14f);
+            ph = (im == 0.f && re < 0.f) ? 3.14159274101257324f : atan2f(im, re);
+        } else {
+            mag = sqrtf(re * re + im * im);
+            ph = atan2f(im, re);
+        }
+        har[b * bs + (long)k * ld + f] = mag;
+        har[b * bs + (long)(11 + k) * ld + f] = ph;
     }
 }
 void launch_stft(const float* har_src, long hs_bs, float* har, long bs, int ld, const int* frames, int B, int Fmax,
-                 hipStream_t s) {
+                 int variant, hipStream_t s) {
     hipLaunchKernelGGL(stft_kernel, dim3((120 * Fmax + 1 + 255) / 256, B), dim3(256), 0, s, har_src, hs_bs, har, bs,
-                       ld, frames);
+                       ld, frames, variant);
     KX_HIP(hipGetLastError());
 }
 
-// head: mag = exp(x[:11]), phase = sin(x[11:]) (Generator.forward), then torch.istft semantics
+// head: mag = exp(x[:11]), phase = sin(x[11:]) (Generator.forward), then the inverse of the chosen variant
 __global__ void istft_spec_kernel(const float* cp, long bs, int ld, float* spec, const int* frames) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y, b = blockIdx.z;
     const int nf = 120 * frames[b] + 1;
@@ -791,7 +824,8 @@ __global__ void istft_spec_kernel(const float* cp, long bs, int ld, float* spec,
     spec[b * bs + (long)k * ld + f] = mag * cosf(ph);
     spec[b * bs + (long)(11 + k) * ld + f] = mag * sinf(ph);
 }
-__global__ void istft_ola_kernel(const float* spec, long bs, int ld, float* audio, long audio_ld, const int* frames) {
+__global__ void istft_ola_kernel(const float* spec, long bs, int ld, float* audio, long audio_ld, const int* frames,
+                                 int variant) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     const int nf = 120 * frames[b] + 1;
     if (j >= 600 * frames[b]) return;
@@ -806,20 +840,20 @@ __global__ void istft_ola_kernel(const float* spec, long bs, int ld, float* audi
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < 11; ++k)
-            acc += c_inv_re[m][k] * sp[(long)k * ld + f] + c_inv_im[m][k] * sp[(long)(11 + k) * ld + f];
+            acc += c_inv_re[variant][m][k] * sp[(long)k * ld + f] + c_inv_im[variant][m][k] * sp[(long)(11 + k) * ld + f];
         y += acc;
         env += c_win_sq[m];
     }
-    audio[b * audio_ld + j] = y / env;
+    audio[b * audio_ld + j] = variant == 0 ? y : y / env;
 }
 void launch_istft_head(const float* cp, long bs, int ld, float* spec_ws, float* audio, long audio_ld,
-                       const int* frames, int B, int Fmax, hipStream_t s) {
+                       const int* frames, int B, int Fmax, int variant, hipStream_t s) {
     const int nfmax = 120 * Fmax + 1;
     hipLaunchKernelGGL(istft_spec_kernel, dim3((nfmax + 255) / 256, 11, B), dim3(256), 0, s, cp, bs, ld, spec_ws,
                        frames);
     KX_HIP(hipGetLastError());
     hipLaunchKernelGGL(istft_ola_kernel, dim3((600 * Fmax + 255) / 256, B), dim3(256), 0, s, spec_ws, bs, ld, audio,
-                       audio_ld, frames);
+                       audio_ld, frames, variant);
     KX_HIP(hipGetLastError());
 }
 

@@ -88,6 +88,8 @@ struct ConvArgs {
     int merge_B;
     float2* stat_part;  // optional [B][Cout][stat_tiles] partial (sum, sum of squares) of the stored values
     int stat_tiles;
+    int ws_force;                  // test hook: 1 = take the wave-specialised kernel when the shape is eligible
+    int ws_ntx, ws_nty, ws_tiles;  // persistent wave-specialised kernel: column tiles, row tiles, all tiles (set by its launcher)
     unsigned long long* stamps;  // diagnostic build only: per-workgroup {t0,t1,t2,t3,hw_id,xcc_id,0,0}
     int dbg;  // timing ablations (env KX_DBG): 1 skip input staging, 2 skip weight copies, 4 skip MFMA, 8 skip epilogue
 };
@@ -111,9 +113,15 @@ void launch_pack_convT(const float* w, float* dst, int Cin, int Cout, int s, int
 size_t packed_conv_floats(int rows, int Cin, int K, int BM);
 
 // f16x3 split path
-enum ConvMode { CONV_F32 = 0, CONV_F16X3 = 1 };
+enum ConvMode { CONV_F32 = 0, CONV_F16X3 = 1, CONV_F16X3_WS = 2 };  // (2: test hook only, f16x3 through conv_f16x3_ws.hip)
 void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStream_t s);
-void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int* bn, int* wn);  // (conv_f16x3.hip)
+void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int stride, int* bn, int* wn,
+                      int ws_force = 0);  // (conv_f16x3.hip)
+// wave-specialised form (conv_f16x3_ws.hip): which launches take it, its tile, its launcher
+bool conv16_use_ws(int BM, int K, int dil, int stride, int merged);       // eligible AND switched on (KX_WS=1)
+bool conv16_ws_eligible(int BM, int K, int dil, int stride, int merged);  // shape fits the kernel
+void conv16_ws_tile(int max_cols, int B, int Cout, int* bn, int* wn);
+void launch_conv1d_f16x3_ws(const ConvArgs& a, int B, int max_cols, hipStream_t s);
 size_t packed_conv16_halves(int rows, int Cin, int K, int BM);
 float device_absmax(const float* p, long n, hipStream_t s);
 int pick_weight_shift(float absmax);
@@ -126,9 +134,9 @@ void launch_transpose_whh(const float* whh, float* out, hipStream_t s);  // [102
 
 void launch_albert_embed(const int64_t* ids, long ids_stride, const float* word, const float* type0,
                          const float* pos, float* out, long bs, int ld, const int* lens, int B, int Tmax,
-                         hipStream_t s);
+                         int n_vocab, unsigned* bad_id, hipStream_t s);
 void launch_embed(const int64_t* ids, long ids_stride, const float* table, int C, float* out, long bs, int ld,
-                  const int* lens, int B, int Tmax, hipStream_t s);
+                  const int* lens, int B, int Tmax, int n_vocab, unsigned* bad_id, hipStream_t s);
 
 enum LnMode { LN_PLAIN = 0, LN_AFFINE = 1, LN_ADA = 2 };
 // channel layer-norm over C rows of [B][C][ld], in place allowed. ADA: g/be are [B][g_bs], (1+g)*xhat+be
@@ -159,7 +167,11 @@ void launch_in_stats(const float* x, long bs, int ld, int C, LenMap len, int B, 
 void launch_style_mix(const float* table, int n_voices, const int* voice_ids, const float* weights, int max_mix,
                       const int* rows, float* styles, int B, hipStream_t s);
 void launch_pack_audio(const float* audio, long audio_ld, const int* frames, int B, int Fmax, int format, void* out,
-                       long out_stride_bytes, hipStream_t s);
+                       long out_stride_bytes, const long* out_off, hipStream_t s);
+// Host output buffers of the kx_infer* calls: page-locked and pooled (one asynchronous D2H copy at PCIe rate instead
+// of per-utterance pageable copies); host_out_free also accepts plain malloc'd pointers (dispatcher results).
+void* host_out_alloc(size_t bytes);
+void host_out_free(void* p);
 void launch_fill_style_rows(float* dst, long bs, int ld, int row0, const float* styles, int style_off,
                             const int* lens, int B, int Tmax, hipStream_t s);
 void launch_copy_rows(const float* src, long sbs, int sld, float* dst, long dbs, int dld, int rows, LenMap len,
@@ -183,10 +195,11 @@ void launch_source(const float* f0, long f0_bs, const int* frames, int B, int Fm
                    const float* lin_b, uint64_t seed, uint64_t utt_base, const uint64_t* utt_seeds, int noise_off,
                    float* phase_ws,
                    float* har, long har_bs, hipStream_t s);
+enum StftVariant { STFT_ONNX = 0, STFT_TORCH = 1 };  // (kernels_misc.hip: the two STFT / iSTFT pairs)
 void launch_stft(const float* har_src, long hs_bs, float* har, long bs, int ld, const int* frames, int B,
-                 int Fmax, hipStream_t s);
+                 int Fmax, int variant, hipStream_t s);
 void launch_istft_head(const float* cp, long bs, int ld, float* spec_ws, float* audio, long audio_ld,
-                       const int* frames, int B, int Fmax, hipStream_t s);
+                       const int* frames, int B, int Fmax, int variant, hipStream_t s);
 void init_dft_tables();
 
 }  // namespace kx

@@ -86,12 +86,17 @@ struct ConvOpts {
     float2* stat_part = nullptr;   // fuse InstanceNorm partial sums of the output into the epilogue
 };
 
+std::vector<unsigned char> read_weight_file(const char* path);  // whole KXHIPW01 file, header checked
+
 class Model {
   public:
     Model(int device);
     ~Model();
     void load_file(const char* path);
-    void load_device_blob(const void* d_blob, size_t n);
+    void load_device_blob(const void* d_blob, size_t n, bool adopt = false);
+    // take ownership of a hipMalloc'd blob BEFORE parsing it, so that it is freed with the model even when the
+    // build throws (kx_create_replicas)
+    void adopt_blob_guard(void* d_blob) { blob_ = static_cast<char*>(d_blob); }
 
     void infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* lens_host, int B,
                       const float* d_styles, const float* speeds_host, int n_speed, uint64_t seed, uint32_t flags,
@@ -124,6 +129,7 @@ class Model {
     std::string last_error;
     uint64_t utt_base = 0;
     int conv_mode = CONV_F16X3;
+    int stft_variant = STFT_ONNX;  // the ONNX export's conv-based STFT pair (what the reference runs)
     int device;
 
   private:
@@ -164,6 +170,7 @@ class Model {
     std::map<std::string, long> fc_off_;
     FcDesc* fc_dev_ = nullptr;
     long gb_total_ = 0;
+    int n_vocab_ = 178;  // rows of the two embedding tables (vocab.rs:5-20)
 
     Arena arenaT_, arenaF_, arenaIO_;
     const uint64_t* d_utt_seeds_ = nullptr;  // per-utterance noise keys of the running call (dispatcher)
@@ -177,6 +184,7 @@ class Model {
     int B_ = 0, Tmax_ = 0, Fmax_ = 0;
     std::vector<int> hT_, hF_;
     int *dT_ = nullptr, *dF_ = nullptr;
+    unsigned* d_bad_id_ = nullptr;  // sticky word: first out-of-table token id seen by the embedding kernels
     float* gb_ = nullptr;  // [B][gb_total_]
     float *nmean_ = nullptr, *nscale_ = nullptr, *nshift_ = nullptr;
     int n_bs_ = 0;

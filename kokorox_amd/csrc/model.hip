@@ -15,6 +15,7 @@ static inline int up4(int x) { return (x + 31) & ~31; }
 
 Model::Model(int dev) : device(dev) {
     if (const char* e = getenv("KOKOROX_CONV")) conv_mode = (strcmp(e, "f32") == 0) ? CONV_F32 : CONV_F16X3;
+    if (const char* e = getenv("KOKOROX_STFT")) stft_variant = (strcmp(e, "torch") == 0) ? STFT_TORCH : STFT_ONNX;
     KX_HIP(hipSetDevice(device));
     KX_HIP(hipStreamCreate(&stream_));
     KX_HIP(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
@@ -78,6 +79,22 @@ static size_t check_header(const unsigned char* h, size_t have) {
     return (size_t)total;
 }
 
+std::vector<unsigned char> read_weight_file(const char* path) {
+    KX_REQUIRE(path && *path, "kx_create: empty weights path");
+    FILE* f = fopen(path, "rb");
+    if (!f) throw Error(2, std::string("cannot open weight file: ") + path);
+    fseek(f, 0, SEEK_END);
+    const size_t n = (size_t)ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<unsigned char> host(n);
+    const size_t got = fread(host.data(), 1, n, f);
+    fclose(f);
+    if (got != n) throw Error(2, std::string("short read on weight file: ") + path);
+    const size_t total = check_header(host.data(), n);
+    if (total != n) throw Error(2, "weight blob: file size does not match header");
+    return host;
+}
+
 void Model::load_file(const char* path) {
     KX_REQUIRE(path && *path, "kx_create: empty weights path");
     FILE* f = fopen(path, "rb");
@@ -99,7 +116,7 @@ void Model::load_file(const char* path) {
     build();
 }
 
-void Model::load_device_blob(const void* d_blob, size_t n) {
+void Model::load_device_blob(const void* d_blob, size_t n, bool adopt) {
     KX_REQUIRE(d_blob && n >= 64, "kx_create_from_device_blob: empty blob");
     KX_HIP(hipSetDevice(device));
     unsigned char h64[64];
@@ -113,9 +130,13 @@ void Model::load_device_blob(const void* d_blob, size_t n) {
     std::vector<unsigned char> hdr(hdr_bytes);
     KX_HIP(hipMemcpy(hdr.data(), d_blob, hdr_bytes, hipMemcpyDeviceToHost));
     parse_table(hdr.data(), hdr_bytes, total, table_);
-    KX_HIP(hipMalloc((void**)&blob_, n));
     blob_bytes_ = n;
-    KX_HIP(hipMemcpy(blob_, d_blob, n, hipMemcpyDeviceToDevice));
+    if (adopt) {  // the caller hands over a hipMalloc'd blob on this device (kx_create_replicas): no second copy
+        blob_ = static_cast<char*>(const_cast<void*>(d_blob));
+    } else {
+        KX_HIP(hipMalloc((void**)&blob_, n));
+        KX_HIP(hipMemcpy(blob_, d_blob, n, hipMemcpyDeviceToDevice));
+    }
     build();
 }
 
@@ -269,6 +290,12 @@ long Model::fc_off(const std::string& key) const {
 }
 
 void Model::build() {
+    {
+        const TensorInfo& we = info("bert.embeddings.word_embeddings.weight");
+        const TensorInfo& te = info("text_encoder.embedding.weight");
+        n_vocab_ = we.dims[0] < te.dims[0] ? we.dims[0] : te.dims[0];  // ids index both tables (178 rows each)
+        KX_REQUIRE(n_vocab_ >= 1, "weight blob: empty embedding table");
+    }
     const std::string L = "bert.encoder.albert_layer_groups.0.albert_layers.0.";
     convs_["bert.map"] = make_conv("bert.encoder.embedding_hidden_mapping_in");
     convs_["bert.qkv"] = make_conv_cat({L + "attention.query", L + "attention.key", L + "attention.value"});
@@ -400,7 +427,7 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
         const int max_c = out.Lmax;
         int bn, wn;
         if (conv_mode == CONV_F16X3) {
-            conv16_pick_tile(w.BM, max_c, B_, w.rows, &bn, &wn);
+            conv16_pick_tile(w.BM, max_c, B_, w.rows, w.K, o.dil, o.stride, &bn, &wn);
         } else {
             bn = conv_bn(w.BM);
             wn = w.BM == 128 ? 2 : 4;
@@ -689,6 +716,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
         A.off = 0;
         dT_ = A.i(B);
         dF_ = A.i(B);
+        d_bad_id_ = reinterpret_cast<unsigned*>(A.i(1));
         d_speeds = A.f(B);
         dur = A.i((size_t)B * 512);
         idx = A.i((size_t)B * idx_ld);
@@ -720,6 +748,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     planT(arenaT_);
 
     KX_HIP(hipMemcpyAsync(dT_, lens_host, B * sizeof(int), hipMemcpyHostToDevice, stream_));
+    KX_HIP(hipMemsetAsync(d_bad_id_, 0, sizeof(unsigned), stream_));
     KX_HIP(hipMemcpyAsync(d_speeds, speeds_host, n_speed * sizeof(float), hipMemcpyHostToDevice, stream_));
     const LenMap LT{dT_, 1, 0};
     auto TT = [&](float* p, int C) {
@@ -743,7 +772,8 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     {
     StreamSwap on_side(stream_, stream2_);
     T t_te0 = TT(te0, 512), t_te1 = TT(te1, 512);
-    launch_embed(d_ids, t_stride, wt("text_encoder.embedding.weight"), 512, te0, t_te0.bs, Tp, dT_, B, Tmax, stream_);
+    launch_embed(d_ids, t_stride, wt("text_encoder.embedding.weight"), 512, te0, t_te0.bs, Tp, dT_, B, Tmax, n_vocab_,
+                 d_bad_id_, stream_);
     T* cur = &t_te0;
     T* nxt = &t_te1;
     for (int i = 0; i < 3; ++i) {
@@ -767,7 +797,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     T t_emb = TT(emb, 128), t_h = TT(h, 768), t_qkv = TT(qkv, 2304), t_ctx = TT(ctx, 768), t_a = TT(av, 768),
       t_f = TT(ff, 2048);
     launch_albert_embed(d_ids, t_stride, wt(E + "word_embeddings.weight"), wt(E + "token_type_embeddings.weight"),
-                        wt(E + "position_embeddings.weight"), emb, t_emb.bs, Tp, dT_, B, Tmax, stream_);
+                        wt(E + "position_embeddings.weight"), emb, t_emb.bs, Tp, dT_, B, Tmax, n_vocab_, d_bad_id_, stream_);
     launch_layernorm_ch(emb, emb, t_emb.bs, Tp, 128, LT, B, Tmax, 1e-12f, LN_AFFINE, wt(E + "LayerNorm.weight"),
                         wt(E + "LayerNorm.bias"), 0, 0.f, stream_);
     tap("bert.emb", t_emb);
@@ -813,10 +843,17 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     launch_duration(logits, t_logits.bs, Tp, d_speeds, n_speed, dT_, d_pinned_, n_pinned_, dur, dF_, idx, idx_ld, B,
                     stream_);
     KX_HIP(hipMemcpyAsync(hF_.data(), dF_, B * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    unsigned bad_id = 0;
+    KX_HIP(hipMemcpyAsync(&bad_id, d_bad_id_, sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
 
     // ===== the one host round trip: predicted frame counts size everything downstream =========
     KX_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));  // the TextEncoder branch joins here
     KX_HIP(hipStreamSynchronize(stream_));
+    if (bad_id) {  // a device-side id outside the embedding tables (clamped for the gather, never read out of bounds)
+        const unsigned w = bad_id - 1;
+        throw Error(1, "infer: token id outside 0.." + std::to_string(n_vocab_ - 1) + " (utterance " + std::to_string(w >> 16) +
+                           ", position " + std::to_string(w & 0xffffu) + ")");
+    }
     int Fmax = 0;
     for (int b = 0; b < B; ++b) Fmax = hF_[b] > Fmax ? hF_[b] : Fmax;
     Fmax_ = Fmax;
@@ -916,7 +953,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
             tap("gen.har_source", hs);
         }
         T har = F121(22);
-        if (!dry_) launch_stft(har_src, hs_ld, har.p, har.bs, har.ld, dF_, B, Fmax, stream_);
+        if (!dry_) launch_stft(har_src, hs_ld, har.p, har.bs, har.ld, dF_, B, Fmax, stft_variant, stream_);
         tap("gen.har", har);
         T x = g0;
         for (int st = 0; st < 2; ++st) {
@@ -961,7 +998,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
         }
         tap("gen.conv_post", cp);
         float* spec = A.f((size_t)B * 22 * F120p);
-        if (!dry_) launch_istft_head(cp.p, cp.bs, cp.ld, spec, d_audio, audio_ld, dF_, B, Fmax, stream_);
+        if (!dry_) launch_istft_head(cp.p, cp.bs, cp.ld, spec, d_audio, audio_ld, dF_, B, Fmax, stft_variant, stream_);
         if (taps_on_ && !dry_) {
             T au;
             au.p = d_audio; au.bs = audio_ld; au.ld = (int)audio_ld; au.C = 1; au.len = LenMap{dF_, 600, 0}; au.Lmax = 600 * Fmax;
@@ -1035,7 +1072,7 @@ void Model::infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* l
         KX_REQUIRE(lens[b] >= 1 && lens[b] <= 512 && lens[b] <= t_stride, "infer: token count must be 1..512");
         for (int t = 0; t < lens[b]; ++t) {
             const int64_t id = ids[b * t_stride + t];
-            KX_REQUIRE(id >= 0 && id < 178, "infer: token id outside 0..177");
+            KX_REQUIRE(id >= 0 && id < n_vocab_, "infer: token id outside 0..177");
         }
         if (by_voice) {
             KX_REQUIRE(lens[b] >= 2, "infer: voice rows need the two 0 pads (row = tokens - 2)");
@@ -1057,6 +1094,7 @@ void Model::infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* l
     int *d_vid, *d_rows;
     float* d_w;
     void* d_packed;
+    long* d_off;
     struct SeedGuard {  // the per-utterance key pointer is valid only during this call
         const uint64_t*& p;
         ~SeedGuard() { p = nullptr; }
@@ -1072,7 +1110,8 @@ void Model::infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* l
         d_vid = A.i((size_t)B * mm);
         d_rows = A.i(B);
         d_w = A.f((size_t)B * mm);
-        d_packed = hc.format == 0 ? nullptr : A.alloc(audio_floats * bytes_per_sample);
+        d_off = static_cast<long*>(A.alloc((size_t)B * 8));
+        d_packed = A.alloc(audio_floats * bytes_per_sample);  // compact output: utterances back to back
         return A.f(audio_floats);
     };
     // worst case length is 50 frames per token; start from a typical 8 and retry once if short
@@ -1112,33 +1151,93 @@ void Model::infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* l
             }
             throw;
         }
-        const char* src = reinterpret_cast<const char*>(d_audio);
-        if (hc.format != 0) {
-            launch_pack_audio(d_audio, ld, dF_, B, Fmax_, hc.format, d_packed, ld * bytes_per_sample, stream_);
-            src = static_cast<const char*>(d_packed);
-        }
-        KX_HIP(hipStreamSynchronize(stream_));
+        // frame counts are known (the forward's one host sync): pack the B waveforms back to back on the GPU in the
+        // requested sample format, then ONE asynchronous copy into a page-locked host buffer
+        std::vector<long> off(B);
         int64_t total = 0;
         for (int b = 0; b < B; ++b) {
             out_samples[b] = (int64_t)600 * hF_[b];
             out_bytes[b] = out_samples[b] * bytes_per_sample;
+            off[b] = (long)total;
             total += out_bytes[b];
         }
-        char* host = static_cast<char*>(malloc((size_t)(total > 0 ? total : 1)));
-        if (!host) throw Error(3, "infer: out of host memory");
-        int64_t o = 0;
-        for (int b = 0; b < B; ++b) {
-            hipError_t e = hipMemcpy(host + o, src + (int64_t)b * ld * bytes_per_sample, (size_t)out_bytes[b],
-                                     hipMemcpyDeviceToHost);
-            if (e != hipSuccess) {
-                free(host);
-                throw Error(3, std::string("infer: D2H copy failed: ") + hipGetErrorString(e));
-            }
-            o += out_bytes[b];
+        KX_HIP(hipMemcpyAsync(d_off, off.data(), (size_t)B * 8, hipMemcpyHostToDevice, stream_));
+        launch_pack_audio(d_audio, ld, dF_, B, Fmax_, hc.format, d_packed, 0, d_off, stream_);
+        char* host = static_cast<char*>(host_out_alloc((size_t)(total > 0 ? total : 1)));
+        hipError_t e = hipMemcpyAsync(host, d_packed, (size_t)total, hipMemcpyDeviceToHost, stream_);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+        if (e != hipSuccess) {
+            host_out_free(host);
+            throw Error(3, std::string("infer: D2H copy failed: ") + hipGetErrorString(e));
         }
         *out = host;
         return;
     }
+}
+
+
+// ---- pooled page-locked host buffers for the results ------------------------------------------------------
+namespace {
+struct HostPool {
+    std::mutex mu;
+    std::map<void*, size_t> cap;             // every live pinned buffer -> capacity
+    std::multimap<size_t, void*> free_list;  // idle ones by capacity
+    size_t idle_bytes = 0;
+    static constexpr size_t kMaxIdle = size_t(1) << 30;
+    ~HostPool() {
+        for (auto& kv : free_list) (void)hipHostFree(kv.second);
+    }
+};
+HostPool& host_pool() {
+    static HostPool* p = new HostPool;  // (leaked on purpose: buffers may outlive static destruction order)
+    return *p;
+}
+}  // namespace
+
+void* host_out_alloc(size_t bytes) {
+    HostPool& P = host_pool();
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.free_list.lower_bound(bytes);
+        if (it != P.free_list.end() && it->first <= 2 * bytes + (1 << 20)) {
+            void* p = it->second;
+            P.idle_bytes -= it->first;
+            P.free_list.erase(it);
+            return p;
+        }
+    }
+    const size_t want = (bytes + (1 << 20) - 1) & ~((size_t(1) << 20) - 1);
+    void* p = nullptr;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess || !p) {
+        (void)hipGetLastError();
+        p = malloc(bytes);  // pageable memory still works with hipMemcpyAsync (staged by the runtime)
+        if (!p) throw Error(3, "infer: out of host memory");
+        return p;
+    }
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.cap[p] = want;
+    return p;
+}
+
+void host_out_free(void* p) {
+    if (!p) return;
+    HostPool& P = host_pool();
+    size_t c = 0;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.cap.find(p);
+        if (it != P.cap.end()) {
+            c = it->second;
+            if (P.idle_bytes + c <= HostPool::kMaxIdle) {
+                P.free_list.emplace(c, p);
+                P.idle_bytes += c;
+                return;
+            }
+            P.cap.erase(it);
+        }
+    }
+    if (c) (void)hipHostFree(p);
+    else free(p);
 }
 
 }  // namespace kx

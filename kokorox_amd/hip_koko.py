@@ -72,6 +72,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_create_from_device_blob": (vp, [vp, sz, i32, cp, sz]),
         "kx_destroy": (None, [vp]),
         "kx_last_error": (cp, [vp]),
+        "kx_last_error_copy": (i32, [vp, cp, sz]),
+        "kx_create_replicas": (i32, [cp, vp, i32, vp, cp, sz]),
         "kx_infer": (i32, [vp, vp, i64, vp, i32, vp, vp, i32, u64, u32, C.POINTER(C.POINTER(f32)), vp]),
         "kx_free_audio": (None, [C.POINTER(f32)]),
         "kx_infer_device": (i32, [vp, vp, i64, vp, i32, vp, vp, i32, u64, u32, vp, i64, vp, C.POINTER(i64)]),
@@ -80,6 +82,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_set_utterance_base": (i32, [vp, u64]),
         "kx_set_conv_mode": (i32, [vp, i32]),
         "kx_get_conv_mode": (i32, [vp]),
+        "kx_set_stft_variant": (i32, [vp, i32]),
+        "kx_get_stft_variant": (i32, [vp]),
         "kx_profile_enable": (i32, [vp, i32]),
         "kx_profile_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "kx_profile_detail": (i32, [vp, vp, i64, C.POINTER(i64)]),
@@ -110,9 +114,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 
 ABI_SYMBOLS = [
-    "kx_version", "kx_init", "kx_create", "kx_create_from_device_blob", "kx_destroy", "kx_last_error", "kx_infer",
+    "kx_version", "kx_init", "kx_create", "kx_create_from_device_blob", "kx_create_replicas", "kx_destroy",
+    "kx_last_error", "kx_last_error_copy", "kx_infer",
     "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_set_utterance_base",
-    "kx_set_conv_mode", "kx_get_conv_mode",
+    "kx_set_conv_mode", "kx_get_conv_mode", "kx_set_stft_variant", "kx_get_stft_variant",
     "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_set_voice_table", "kx_infer_voices",
     "kx_infer_packed", "kx_free_packed", "kx_dispatcher_create", "kx_dispatcher_submit",
     "kx_dispatcher_stats", "kx_dispatcher_destroy", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test_attention", "kx_test_conv1d_epilogue",
@@ -157,6 +162,28 @@ class HipKoko:
         if not h:
             raise RuntimeError(f"Failed to create Kokoro TTS model: {err.value.decode()}")
         return cls("", device, _handle=h)
+
+    @classmethod
+    def replicas(cls, model_path: str, devices: Sequence[int]) -> List["HipKoko"]:
+        """One model per entry of `devices` from ONE read of the weight file: upload to devices[0], device-to-device
+        fan-out to the others inside the library (kx_create_replicas).  The list is what `Dispatcher` takes; the
+        reference's server is one process holding every GPU (kokorox-openai/src/lib.rs:370-439)."""
+        lib = load_library()
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        if dev.ndim != 1 or dev.shape[0] < 1:
+            raise ValueError("replicas: at least one device id")
+        out = (C.c_void_p * dev.shape[0])()
+        err = C.create_string_buffer(512)
+        rc = lib.kx_create_replicas(os.fsencode(model_path), _ptr(dev), dev.shape[0], out, err, len(err))
+        if rc != 0:
+            raise RuntimeError(f"Failed to create Kokoro TTS model: {err.value.decode()}")
+        return [cls("", int(d), _handle=out[i]) for i, d in enumerate(dev)]
+
+    def last_error(self) -> str:
+        """Thread-safe copy of the model's last failure text (kx_last_error_copy)."""
+        buf = C.create_string_buffer(512)
+        self._lib.kx_last_error_copy(self._h, buf, len(buf))
+        return buf.value.decode()
 
     def infer(self, tokens: Sequence[Sequence[int]], styles: Sequence[Sequence[float]], speed: float,
               seed: int = 0, flags: int = 0):
@@ -283,6 +310,13 @@ class HipKoko:
     def get_conv_mode(self) -> int:
         return int(self._lib.kx_get_conv_mode(self._h))
 
+    def set_stft_variant(self, variant: int):
+        """0 = the ONNX export's conv-based STFT pair (default), 1 = torch.stft / torch.istft semantics."""
+        self._check(self._lib.kx_set_stft_variant(self._h, variant))
+
+    def get_stft_variant(self) -> int:
+        return int(self._lib.kx_get_stft_variant(self._h))
+
     def set_utterance_base(self, base: int):
         self._check(self._lib.kx_set_utterance_base(self._h, base))
 
@@ -322,7 +356,7 @@ class HipKoko:
 
     def _check(self, rc: int):
         if rc != 0:
-            raise KokoroxHipError(rc, self._lib.kx_last_error(self._h).decode())
+            raise KokoroxHipError(rc, self.last_error())
 
 
 class Dispatcher:
@@ -381,6 +415,7 @@ def _err_call(fn, *args):
 
 
 CONV_F32, CONV_F16X3 = 0, 1
+STFT_ONNX, STFT_TORCH = 0, 1
 
 
 def conv1d(x, w, bias=None, stride=1, pad=0, dil=1, transposed=False, act=0, slope=0.0, alpha=None, norm=None,

@@ -23,9 +23,17 @@ Choices where the published model leaves freedom (all stated so the HIP path can
     so that CPU and GPU draw identical values (SURVEY.md §7 hard part 2).  Upstream's
     random initial phase is added at sample 0 only and is discarded by the 1/300 linear
     down-sampling that follows (it reads samples 300i+149/150), so it has no effect.
-  * forward STFT follows the ONNX export's conv formulation (custom_stft.py): centre
-    padding = replicate, periodic Hann, phase = atan2(imag, real); the DFT basis uses
-    exact 0/±1 at quadrant angles so the Nyquist/DC imaginary parts are exactly +0.
+  * STFT pair: upstream has two.  stft_variant="onnx" (default) follows the ONNX export's
+    conv formulation in BOTH directions (custom_stft.py: replicate centre padding, periodic
+    Hann, magnitude sqrt(re^2+im^2+1e-14), phase atan2 with imag==0 & real<0 forced to +pi;
+    inverse = two conv_transpose1d with cos/sin*window/n_fft summed as real - imag, centre
+    trimmed: no one-sided doubling, no window-envelope division) - that is the graph the
+    reference runs.  stft_variant="torch" keeps the same forward basis but the plain root /
+    atan2 and torch.istft semantics for the inverse (the PyTorch checkpoint's path).  Round 1
+    mixed the two (custom forward, torch inverse); both are recalled from memory and which
+    one the shipped model.onnx holds is the first thing to check against a real file.
+    The DFT basis uses exact 0/+-1 at quadrant angles so the Nyquist/DC imaginary parts
+    are exactly +0.
   * InstanceNorm affine parameters of AdaIN1d are identity (upstream sets affine=True
     only to work around an exporter bug and never trains them).
 """
@@ -113,9 +121,14 @@ def hann_periodic(n: int = 20) -> np.ndarray:
 class KokoroOracle:
     """fp32 (default) or fp64 CPU forward with named intermediate taps."""
 
-    def __init__(self, weights, dtype=torch.float32):
+    def __init__(self, weights, dtype=torch.float32, stft_variant="onnx"):
+        """stft_variant: "onnx" = the conv-based STFT pair of the ONNX export (upstream custom_stft.py, what the
+        reference's `model.onnx` contains: hf_cache.rs:8-10), "torch" = torch.stft / torch.istft semantics (the
+        PyTorch checkpoint with disable_complex=False).  Both are restated from memory; see the module header."""
         if isinstance(weights, str):
             weights = load_blob(weights)
+        assert stft_variant in ("onnx", "torch")
+        self.stft_variant = stft_variant
         self.dt = dtype
         self.w = {k: torch.from_numpy(np.asarray(v)).to(dtype) for k, v in weights.items()}
         self._lstm_cache = {}
@@ -137,6 +150,10 @@ class KokoroOracle:
         self.inv_re = torch.tensor(inv_re.astype(np.float32)).to(dtype)
         self.inv_im = torch.tensor(inv_im.astype(np.float32)).to(dtype)
         self.win_sq = torch.tensor((win * win).astype(np.float32)).to(dtype)
+        # custom_stft.py inverse: cos / sin * window / n_fft for EVERY one-sided bin, combined as real - imag
+        # (no doubling of the interior bins, no division by the window envelope)
+        self.cinv_re = torch.tensor((c[m.T] / 20.0 * win[:, None]).astype(np.float32)).to(dtype)
+        self.cinv_im = torch.tensor((-s[m.T] / 20.0 * win[:, None]).astype(np.float32)).to(dtype)
 
     # -- primitives ----------------------------------------------------------------------
     def _lin(self, x, name):
@@ -282,15 +299,30 @@ class KokoroOracle:
         xp = F.pad(x[None, None], (10, 10), mode="replicate")
         re = F.conv1d(xp, self.fwd_re, stride=5)[0]
         im = F.conv1d(xp, self.fwd_im, stride=5)[0]
-        mag = torch.sqrt(re * re + im * im)
-        ph = torch.atan2(im, re)
+        if self.stft_variant == "onnx":
+            # custom_stft.py transform(): epsilon inside the root, and ONNX's atan2 repaired to PyTorch's value on
+            # the negative real axis (imag exactly 0, real < 0 -> +pi)
+            mag = torch.sqrt(re * re + im * im + 1e-14)
+            ph = torch.atan2(im, re)
+            ph = torch.where((im == 0) & (re < 0), torch.full_like(ph, np.pi), ph)
+        else:
+            mag = torch.sqrt(re * re + im * im)
+            ph = torch.atan2(im, re)
         return torch.cat([mag, ph], dim=0)
 
     def istft(self, mag, ph):
-        """mag, ph [11, n_frames] -> waveform [5*(n_frames-1)] (torch.istft semantics)."""
+        """mag, ph [11, n_frames] -> waveform [5*(n_frames-1)]: custom_stft.py inverse() ("onnx": two transposed
+        convolutions, real - imag, centre trim) or torch.istft semantics ("torch")."""
         nf = mag.shape[1]
         re = mag * torch.cos(ph)
         im = mag * torch.sin(ph)
+        if self.stft_variant == "onnx":
+            y = self.cinv_re @ re + self.cinv_im @ im           # [20, nf]: conv_transpose1d taps, real - imag
+            total = 5 * (nf - 1) + 20
+            out = torch.zeros(total, dtype=self.dt)
+            for n in range(20):
+                out[n: n + 5 * nf: 5] += y[n]
+            return out[10: 10 + 5 * (nf - 1)]
         y = self.inv_re @ re + self.inv_im @ im                 # [20, nf], window applied
         total = 5 * (nf - 1) + 20
         out = torch.zeros(total, dtype=self.dt)

@@ -31,3 +31,26 @@ def test_cpp_host_matches_ctypes(hip_model, blob_path, golden, tmp_path):
     ref = hip_model.infer([list(g["ids"])], [list(g["style"])], 1.0, seed=2)
     assert f"samples={ref.shape[0]} fnv1a={_fnv1a(ref):016x}" in r.stdout
     assert "empty-input=error" in r.stdout
+
+
+def test_cpp_replicas_and_dispatcher_over_two_models(hip_model, blob_path, golden, tmp_path):
+    """kx_create_replicas (one file read, n models) + a dispatcher over more than one model, from compiled C++.
+    On the 1-GPU box both models live on device 0; every request must equal the same request run alone."""
+    lib_dir = os.path.join(ROOT, "kokorox_amd", "lib")
+    exe = str(tmp_path / "replicas_demo")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+                    "-I", "/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "replicas_demo.cpp"), "-L", lib_dir,
+                    "-lkokorox_hip", "-L", "/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib",
+                    "-lpthread", "-o", exe], check=True)
+    g = golden["hello_world"]
+    style = str(tmp_path / "style.f32")
+    g["style"].astype("<f4").tofile(style)
+    r = subprocess.run([exe, blob_path, style, "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "models=2 requests=8" in r.stdout
+    row = [0, 50, 83, 54, 156, 57, 135, 3, 16, 65, 156, 87, 158, 54, 46, 5, 0]
+    hip_model.set_utterance_base(0)
+    for i in range(8):
+        ids = row[:5 + i] + [0]
+        ref = hip_model.infer([ids], [list(g["style"])], 1.0, seed=100 + i)
+        assert f"req{i} rc=0 samples={ref.shape[0]} fnv1a={_fnv1a(ref):016x}" in r.stdout, r.stdout

@@ -152,6 +152,117 @@ def test_pinned_durations_and_full_size_properties(hip_model):
         np.testing.assert_array_equal(a, b)
 
 
+def _teacher_forced_oracle_check(hip_model, oracle, ids, style, got_wave, utt, pinned):
+    """The parity protocol of _ragged_batch_vs_oracle on ONE utterance whose taps are in the model (B = 1 call)."""
+    taps = {}
+    _, dur = oracle.forward(ids, style, 1.0, seed=2, utt=utt, taps=taps, pinned_dur=pinned)
+    assert got_wave.shape[0] == 600 * int(dur.sum())
+    for name in FRONT:
+        ref = taps[name].numpy()
+        got = hip_model.tap(name, 0)
+        assert got.shape == ref.shape, name
+        assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), name
+    f0 = hip_model.tap("pred.F0", 0)
+    ref_f0 = taps["pred.F0"].numpy()
+    assert np.abs(f0 - ref_f0).max() <= 5e-5 * np.abs(ref_f0).max()
+    n_c = hip_model.tap("pred.N", 0)[0]
+    taps2 = {}
+    oracle.forward(ids, style, 1.0, seed=2, utt=utt, taps=taps2, pinned_dur=pinned, f0_override=f0[0], n_override=n_c)
+    assert np.abs(hip_model.tap("gen.har_source", 0) - taps2["gen.har_source"].numpy()).max() < 2e-6
+    har = hip_model.tap("gen.har", 0)
+    assert _wrapped_diff(har, taps2["gen.har"].numpy()).max() < 2e-3
+    taps3 = {}
+    audio3, _ = oracle.forward(ids, style, 1.0, seed=2, utt=utt, taps=taps3, pinned_dur=pinned, f0_override=f0[0],
+                               n_override=n_c, har_override=har)
+    for name in BACK:
+        ref = taps3[name].numpy()
+        got = hip_model.tap(name, 0)
+        assert got.shape == ref.shape, name
+        assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), name
+    assert np.abs(got_wave - audio3.numpy()).max() < TOL_WAVE
+
+
+def test_baseline_workload_at_size_batch64_and_batch1(hip_model, oracle):
+    """BASELINE configs[1] and configs[2] at full size (T = 130, durations pinned 3,3,3,4 -> F = 422):
+      * B = 64 in one call: frames, finiteness;
+      * every one of the 64 equals, bit for bit, its own B = 1 call (that call runs the small-grid tile path at
+        full length: one 128-phoneme utterance on one MI355X);
+      * utterances 0, 31 and 63 are compared with the CPU oracle under the teacher-forcing protocol (every tap and
+        the waveform, |d| < 1e-4)."""
+    from oracle import kokoro_ref as R
+    from kokorox_amd import hip_koko as hk
+    from kokorox_amd import weights as W
+    B = 64
+    ids = R.synthetic_inputs(B, 128, seed=0)
+    voices = W.synthetic_voices(4)
+    styles = [voices[b % 4, 128, 0] for b in range(B)]
+    pinned = R.pinned_durations(130)
+    hip_model.set_pinned_durations([3, 3, 3, 4])
+    try:
+        hip_model.set_utterance_base(0)
+        outs = hip_model.infer_batch([list(x) for x in ids], styles, [1.0], seed=2)
+        assert len(outs) == B
+        for b in range(B):
+            assert outs[b].shape[0] == 600 * 422 and np.isfinite(outs[b]).all()
+        for b in range(B):
+            hip_model.set_utterance_base(b)  # noise key (seed, b), as inside the batch
+            checked = b in (0, 31, 63)
+            one = hip_model.infer([list(ids[b])], [styles[b]], 1.0, seed=2, flags=hk.KX_FLAG_TAPS if checked else 0)
+            np.testing.assert_array_equal(one, outs[b], err_msg=f"utterance {b}: batch of 64 != batch of 1")
+            if checked:
+                _teacher_forced_oracle_check(hip_model, oracle, ids[b], styles[b], one, b, pinned)
+    finally:
+        hip_model.set_utterance_base(0)
+        hip_model.set_pinned_durations(None)
+
+
+def test_device_entry_point_rejects_bad_ids(hip_model):
+    """kx_infer_device takes ids from device memory: the embedding kernels range-check them (clamped gather, sticky
+    error word) and the call returns KX_ERR_INVALID instead of reading out of bounds."""
+    import torch
+    from kokorox_amd import hip_koko as hk
+    ids = torch.tensor([[0, 5, 500, 7, 0], [0, 9, 9, 9, 0]], dtype=torch.int64, device="cuda")
+    styles = torch.zeros((2, 256), dtype=torch.float32, device="cuda")
+    audio = torch.zeros((2, 600 * 5 * 50), dtype=torch.float32, device="cuda")
+    frames = torch.zeros(2, dtype=torch.int32, device="cuda")
+    lens = np.array([5, 5], dtype=np.int32)
+    with pytest.raises(hk.KokoroxHipError, match="token id outside 0..177.*utterance 0, position 2") as ei:
+        hip_model.infer_device(ids.data_ptr(), 5, lens, styles.data_ptr(), np.array([1.0], np.float32),
+                               audio.data_ptr(), audio.shape[1], frames.data_ptr())
+    assert ei.value.code == 1
+    ids[0, 2] = -3
+    with pytest.raises(hk.KokoroxHipError, match="token id"):
+        hip_model.infer_device(ids.data_ptr(), 5, lens, styles.data_ptr(), np.array([1.0], np.float32),
+                               audio.data_ptr(), audio.shape[1], frames.data_ptr())
+    ids[0, 2] = 6  # the same buffers work once the id is valid
+    hip_model.infer_device(ids.data_ptr(), 5, lens, styles.data_ptr(), np.array([1.0], np.float32),
+                           audio.data_ptr(), audio.shape[1], frames.data_ptr())
+    hip_model.sync()
+    assert int(frames.min()) >= 5 and torch.isfinite(audio).all()
+
+
+def test_last_error_is_a_per_thread_copy(hip_model):
+    """kx_last_error returns storage of the calling thread; concurrent failures on one model do not tear it."""
+    import threading
+    from kokorox_amd import hip_koko as hk
+    style = [0.0] * 256
+    seen = []
+
+    def worker(tok):
+        for _ in range(20):
+            try:
+                hip_model.infer([[0, tok, 0]], [style], 1.0)
+            except hk.KokoroxHipError as e:
+                seen.append(str(e))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in (500, 900, 1234)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert len(seen) == 60 and all("token id outside" in m for m in seen)
+
+
 def test_max_length_utterance(hip_model):
     """510 tokens + 2 pads is the model limit (voice table rows, hf_cache.rs:302-309)."""
     from oracle import kokoro_ref as R

@@ -27,7 +27,7 @@ CONV_CASES = [
 ]
 
 
-MODES = [pytest.param(0, id="f32"), pytest.param(1, id="f16x3")]
+MODES = [pytest.param(0, id="f32"), pytest.param(1, id="f16x3"), pytest.param(2, id="f16x3ws")]
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -182,7 +182,7 @@ def test_conv1d_tile_border_sweep(B, Cin, Cout, L, k, p, d):
     b = rng.standard_normal(Cout, dtype=np.float32)
     ref = F.conv1d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
                    padding=p, dilation=d).numpy()
-    for mode in (1, 0):
+    for mode in (1, 0, 2):
         y = hk.conv1d(x, w, b, pad=p, dil=d, mode=mode)
         assert y.shape == ref.shape
         assert np.abs(y - ref).max() < 2e-5, (mode, np.abs(y - ref).max())

@@ -98,6 +98,36 @@ def test_c_abi_exports_every_declared_symbol():
     assert b"gfx950" in lib.kx_version()
 
 
+def _split_args(arglist: str):
+    """Top-level comma split of a parameter list (no nested parentheses in this ABI)."""
+    a = [x.strip() for x in arglist.replace("\n", " ").split(",")]
+    return [] if a in ([""], ["void"]) else a
+
+
+def test_rust_crate_binds_the_header_name_for_name():
+    """kokorox-hip/src/lib.rs (source only: no cargo in this image) declares every non-test entry point of
+    include/kokorox_hip.h with the same number of parameters, and nothing the header lacks."""
+    hdr = open(os.path.join(ROOT, "include", "kokorox_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    c_decl = {m.group(1): _split_args(m.group(2))
+              for m in re.finditer(r"\b(kx_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", hdr)}
+    rs = open(os.path.join(ROOT, "kokorox-hip", "src", "lib.rs"), encoding="utf-8").read()
+    ext = re.search(r'extern "C" \{(.*?)\n\}', rs, flags=re.S).group(1)
+    rs_decl = {m.group(1): _split_args(m.group(2)) for m in re.finditer(r"\bfn (kx_[a-z0-9_]+)\s*\(([^()]*)\)", ext)}
+    assert len(rs_decl) >= 25
+    for name, args in rs_decl.items():
+        assert name in c_decl, f"lib.rs binds {name}, which include/kokorox_hip.h does not declare"
+        assert len(args) == len(c_decl[name]), f"{name}: {len(args)} parameters in lib.rs, {len(c_decl[name])} in the header"
+    product = {n for n in c_decl if not n.startswith("kx_test_") and n != "kx_debug_tap"}
+    assert product <= set(rs_decl), f"lib.rs lacks {sorted(product - set(rs_decl))}"
+    # pointer-vs-value agreement for every parameter (a `*` on one side means a `*` on the other)
+    for name in product:
+        for ca, ra in zip(c_decl[name], rs_decl[name]):
+            assert ("*" in ca) == ("*" in ra), f"{name}: `{ca}` vs `{ra}`"
+    for f in ("Cargo.toml", "build.rs"):
+        assert os.path.exists(os.path.join(ROOT, "kokorox-hip", f))
+
+
 def test_no_gpu_fails_loudly():
     """The product path has no CPU fallback: without a device, init/create report an error."""
     import torch

@@ -38,7 +38,7 @@ def test_oracle_matches_golden(oracle, golden):
         np.testing.assert_array_equal(dur.numpy(), g["pred_dur"])
         assert audio.shape[0] == 600 * int(g["pred_dur"].sum())
         for k in g:
-            if k.startswith("tap:"):
+            if k.startswith("tap:") and k[4:] in taps:
                 ref = g[k]
                 got = taps[k[4:]].numpy()
                 scale = max(1.0, float(np.abs(ref).max()))
@@ -52,6 +52,12 @@ def test_oracle_matches_golden(oracle, golden):
                                    f0_override=g["tap:pred.F0"][0], n_override=g["tap:pred.N"][0])
         np.testing.assert_allclose(taps2["gen.har_source"].numpy(), g["tap:gen.har_source"], atol=2e-6)
         assert np.abs(audio2.numpy() - g["tap:audio"][0]).max() < 1e-4
+        # the other STFT pair (torch.stft / torch.istft semantics) has its own fixture
+        o_t = R.KokoroOracle(oracle.w, stft_variant="torch")
+        audio_t, _ = o_t.forward(g["ids"], g["style"], float(g["speed"]), seed=int(g["seed"]), utt=0,
+                                 f0_override=g["tap:pred.F0"][0], n_override=g["tap:pred.N"][0])
+        assert np.abs(audio_t.numpy() - g["tap:audio_torch_stft"][0]).max() < 1e-4
+        assert np.abs(audio_t.numpy() - audio2.numpy()).max() > 1e-3  # (the two pairs are NOT interchangeable)
 
 
 def test_oracle_fp64_agrees_on_well_conditioned_stages(oracle, blob_path, golden):
@@ -74,13 +80,34 @@ def test_oracle_fp64_agrees_on_well_conditioned_stages(oracle, blob_path, golden
 
 
 def test_stft_istft_roundtrip(oracle):
-    """Size-independent property of the analysis/synthesis pair: istft(stft(x)) == x."""
+    """Size-independent properties of the two analysis/synthesis pairs.
+    torch variant: istft(stft(x)) == x.  ONNX-export variant (custom_stft.py): the inverse neither doubles the
+    interior one-sided bins nor divides by the window envelope, so a tone on an interior bin comes back as
+    1/2 * (sum of squared Hann over 4 overlapping frames = 1.5) = 0.75 x, and the map is linear."""
     torch.manual_seed(0)
     x = torch.randn(600 * 3)
-    s = oracle.stft(x)
-    y = oracle.istft(s[:11], s[11:])
+    o_t = R.KokoroOracle(oracle.w, stft_variant="torch")
+    s = o_t.stft(x)
+    y = o_t.istft(s[:11], s[11:])
     assert y.shape == x.shape
     assert float((x - y).abs().max()) < 1e-5
+    assert oracle.stft_variant == "onnx"
+    n = torch.arange(1800, dtype=torch.float32)
+    tone = torch.cos(2 * np.pi * 3 * n / 20) + 0.5 * torch.sin(2 * np.pi * 7 * n / 20)
+    s = oracle.stft(tone)
+    y = oracle.istft(s[:11], s[11:])
+    assert y.shape == tone.shape
+    assert float((y - 0.75 * tone)[40:-40].abs().max()) < 5e-5
+    s2 = oracle.stft(x)
+    # the magnitude carries custom_stft's epsilon: sqrt(re^2 + im^2 + 1e-14) >= 1e-7
+    assert float(s2[:11].min()) >= 1e-7 * 0.999
+
+
+def test_onnx_stft_phase_on_the_negative_real_axis(oracle):
+    """custom_stft.py forces atan2 to +pi where imag == 0 and real < 0 (ONNX's Atan2 would give -pi for -0)."""
+    x = -torch.ones(100)  # constant negative signal: bin 0 is real < 0, imag exactly 0 (exact quadrant basis)
+    s = oracle.stft(x)
+    assert torch.all(s[11, 2:-2] == np.float32(np.pi))
 
 
 def test_source_is_linear_free_of_random_phase(oracle):

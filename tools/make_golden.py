@@ -65,6 +65,11 @@ def main():
                "pred_dur": dur.numpy().astype(np.int64), "weights_seed": np.int64(1234)}
         for t in TAPS:
             out["tap:" + t] = taps[t].numpy().astype(np.float32)
+        # the same utterance through the other STFT pair (torch.stft / torch.istft semantics), F0 / N curves pinned
+        o_t = R.KokoroOracle(blob, stft_variant="torch")
+        audio_t, _ = o_t.forward(ids, style, speed, seed=2, utt=0, f0_override=taps["pred.F0"][0].numpy(),
+                                 n_override=taps["pred.N"][0].numpy())
+        out["tap:audio_torch_stft"] = audio_t.numpy().astype(np.float32)[None]
         np.savez_compressed(os.path.join(GOLD, f"forward_{name}.npz"), **out)
         print(name, "F =", int(dur.sum()), "samples =", audio.shape[0], "max|a| =", float(audio.abs().max()))
     # Philox / Box-Muller stream (first values), pins the noise definition shared with the HIP kernel
