@@ -44,7 +44,10 @@ bool conv16_use_ws(int BM, int K, int dil, int stride, int merged) {
 // older - in particular the piece the consumers read NEXT step - has landed (vector memory operations of a wave
 // complete in order).
 template <int EXTRA>
-__device__ __forceinline__ void ws_producer_barrier(int ng) {
+__device__ __forceinline__ void ws_producer_barrier(int ng, bool skip = false) {
+    if (skip) {  // timing ablation (KX_DBG bit 16): no waits, no barriers
+        return;
+    }
     switch (ng) {
         case 0: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(EXTRA + 0) : "memory"); break;
         case 2: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(EXTRA + 2) : "memory"); break;
@@ -217,6 +220,7 @@ void conv1d_f16x3_ws_kernel(const ConvArgs a) {
             // until the previous LDS-DMA instruction has consumed it) and the producers were the last wave at every
             // barrier.  Returns the number of copy instructions issued by this wave.
             const int g0 = g;
+            const bool nobar = (a.dbg & 16) != 0;
             const uint4* wbase = reinterpret_cast<const uint4*>(a.w16) + (long)ct * n_chunks * K * tap_units;
             auto issue_piece = [&](int s) -> int {
                 if (s >= n_steps || (a.dbg & 2)) return 0;
@@ -262,9 +266,9 @@ void conv1d_f16x3_ws_kernel(const ConvArgs a) {
             stage(0);
             if (n_chunks > 1) {
                 load_raw(1);
-                ws_producer_barrier<NRAW>(0);
+                ws_producer_barrier<NRAW>(0, nobar);
             } else {
-                ws_producer_barrier<0>(0);
+                ws_producer_barrier<0>(0, nobar);
             }
             int s = 0;
             for (int ch = 0; ch < n_chunks; ++ch) {
@@ -273,15 +277,15 @@ void conv1d_f16x3_ws_kernel(const ConvArgs a) {
                     if (ch + 2 < n_chunks) {
                         load_raw(ch + 2);
                         asm volatile("" ::: "memory");  // keep the copies below behind the loads (vmcnt order)
-                        ws_producer_barrier<NRAW>(issue_piece(s + 2));
+                        ws_producer_barrier<NRAW>(issue_piece(s + 2), nobar);
                     } else {
-                        ws_producer_barrier<0>(issue_piece(s + 2));
+                        ws_producer_barrier<0>(issue_piece(s + 2), nobar);
                     }
                 } else {
-                    ws_producer_barrier<0>(issue_piece(s + 2));
+                    ws_producer_barrier<0>(issue_piece(s + 2), nobar);
                 }
                 ++s;
-                for (int pc = 1; pc < n_pieces; ++pc, ++s) ws_producer_barrier<0>(issue_piece(s + 2));
+                for (int pc = 1; pc < n_pieces; ++pc, ++s) ws_producer_barrier<0>(issue_piece(s + 2), nobar);
             }
             g += n_steps;
         }
@@ -314,7 +318,7 @@ void conv1d_f16x3_ws_kernel(const ConvArgs a) {
         __builtin_amdgcn_s_setprio(2);
         // chunk 0 is in LDS; so is the tile's first weight piece (written in the last step of the previous tile, or
         // - first tile - just above: this wave's part of it must have been performed before the barrier)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!(a.dbg & 16)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (stamp) {
             sr1 = __builtin_amdgcn_s_memrealtime();
             sc1 = __builtin_readcyclecounter();
@@ -373,7 +377,7 @@ void conv1d_f16x3_ws_kernel(const ConvArgs a) {
                 const unsigned long long tb = __builtin_readcyclecounter();
                 asm volatile("s_barrier" ::: "memory");
                 bar_cyc += __builtin_readcyclecounter() - tb;
-            } else {
+            } else if (!(a.dbg & 16)) {
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
         }
