@@ -83,7 +83,7 @@ def pmc_traffic(B, T, F, mode):
     return None if best is None else best["traffic_bytes_per_launch"]
 
 
-def roofline(f16x3, conv_flops, conv_ms, n_launch, steps, wall, B, T, F):
+def roofline(f16x3, conv_flops, conv_ms, n_launch, steps, wall, B, T, F, conv_bytes=0.0):
     """Dominant kernel = the BM=128 family of the conv1d implicit-GEMM kernel (HIP events in the library).
 
     achieved = ALGORITHMIC FLOPs (2*Cout*Cin*k*L per launch) / measured time.  In f16x3 mode every
@@ -95,8 +95,16 @@ def roofline(f16x3, conv_flops, conv_ms, n_launch, steps, wall, B, T, F):
     peak = PEAK_F16_MFMA_TFLOPS if f16x3 else PEAK_F32_MFMA_TFLOPS
     kern = ("kx::conv1d_f16x3_kernel<128,{256|128},2,2,ACT> (f16 32x32x16 MFMA x3, implicit GEMM)" if f16x3
             else "kx::conv1d_mfma_kernel<128,128,2,2> (f32 32x32x2 MFMA implicit GEMM)")
+    traffic = pmc_traffic(B, T, F, "f16x3" if f16x3 else "f32")
+    alg_bytes = conv_bytes / max(n_launch, 1)
     out = {"bound": "mfma", "kernel": kern, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-           "traffic": pmc_traffic(B, T, F, "f16x3" if f16x3 else "f32"),
+           "traffic": traffic,
+           # algorithmic HBM bytes per launch (each conv reads its input, its residual / running sum
+           # where the epilogue uses them and its weights once, and writes its output once; logged per launch by the
+           # library) and how much more the PMC counters saw: > 1 = re-reads (window overlap, one staging per row tile)
+           "algorithmic_bytes_per_launch": alg_bytes,
+           "traffic_over_algorithmic": (traffic / alg_bytes) if (traffic and alg_bytes > 0) else None,
+           "algorithmic_gb_per_s": alg_bytes / max(conv_ms / max(n_launch, 1) * 1e-3, 1e-12) / 1e9,
            "launches_per_step": n_launch / max(steps, 1), "avg_launch_ms": conv_ms / max(n_launch, 1),
            "gflop_per_launch": conv_flops / max(n_launch, 1) / 1e9, "kernel_share_of_wall": conv_ms * 1e-3 / wall}
     if f16x3:
@@ -225,19 +233,22 @@ def main():
     wall = time.perf_counter() - t0
     progress(f"{a.steps} timed steps: {wall:.3f} s")
     n_launch, conv_ms, conv_flops = model.profile_read()
+    stats_launches, stats_bytes = model.profile_aux()
     f16x3 = model.get_conv_mode() == 1
+    det = model.profile_detail()
+    conv_bytes = float(det[:, 9].sum()) if len(det) else 0.0
     if a.detail and rank == 0:
-        det = model.profile_detail()
         per = len(det) // max(a.steps, 1)
         agg = {}
         for r in det[-per:]:
             key = tuple(int(v) for v in r[:6])
-            t = agg.setdefault(key, [0, 0.0, 0.0])
-            t[0] += 1; t[1] += r[7]; t[2] += r[8]
+            t = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
+            t[0] += 1; t[1] += r[7]; t[2] += r[8]; t[3] += r[9]
         with open(a.detail, "w") as f:
-            f.write("rows Cin taps dil stride store launches GFLOP ms TFLOP/s\n")
-            for key, (n, fl, ms) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
-                f.write(" ".join(f"{v:5d}" for v in key) + f" {n:4d} {fl / 1e9:10.1f} {ms:9.3f} {fl / ms / 1e9:8.1f}\n")
+            f.write("rows Cin taps dil stride store launches GFLOP ms TFLOP/s alg_GB alg_GB/s\n")
+            for key, (n, fl, ms, by) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+                f.write(" ".join(f"{v:5d}" for v in key) + f" {n:4d} {fl / 1e9:10.1f} {ms:9.3f} {fl / ms / 1e9:8.1f}"
+                        f" {by / 1e9:8.2f} {by / ms / 1e6:8.0f}\n")
     model.profile_enable(False)
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
@@ -289,14 +300,15 @@ def main():
         w2 = time.perf_counter() - t2
         a_s = sum(len(o) for o in outs) / 24000.0
         pcie = {"rtf": a_s / w2, "ms_per_step": w2 * 1e3, "audio_s": a_s,
-                "note": "host buffers in and out (pageable), incl. the ctypes marshalling of this script"}
+                "note": "host buffers in (pageable) and out (one async D2H of the packed batch into pooled page-locked "
+                        "memory), incl. the ctypes marshalling and the per-utterance numpy copies of this script"}
         progress(f"host-buffer step: {w2:.3f} s")
         del outs
 
     if rank == 0:
         flops_per_utt = (0.1635 * T + 1.317 * F) * 1e9  # SURVEY.md §8d model
         out = {
-            "metric": "real-time factor (audio-s/wall-s), 24 kHz, batch=64",
+            "metric": f"real-time factor (audio-s/wall-s), 24 kHz, batch={B}",
             "value": rtf,
             "unit": "x realtime",
             "n_gpus": world,
@@ -319,7 +331,10 @@ def main():
             "finite": finite,
             "weight_broadcast_s": t_bcast,
             "model_tflops": flops_per_utt * world * B * a.steps / wall / 1e12,
-            "roofline": roofline(f16x3, conv_flops, conv_ms, n_launch, a.steps, wall, B, T, F),
+            "roofline": roofline(f16x3, conv_flops, conv_ms, n_launch, a.steps, wall, B, T, F, conv_bytes),
+            # unfused InstanceNorm statistics passes of the timed steps: each reads its tensor once (the known byte
+            # count tools/summarize_pmc.py checks FETCH_SIZE against)
+            "in_stats": {"launches_per_step": stats_launches / max(a.steps, 1), "bytes_per_step": stats_bytes / max(a.steps, 1)},
             "free_running": free,
             "pcie_inclusive": pcie,
         }

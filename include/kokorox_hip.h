@@ -147,9 +147,13 @@ int kx_set_utterance_base(kx_model* m, uint64_t utt_base);
  * FLOPs (2*Cout*Cin*k*columns per launch) since the last read. */
 int kx_profile_enable(kx_model* m, int on);
 int kx_profile_read(kx_model* m, int64_t* launches, double* total_ms, double* total_flops);
-/* Per-launch records of the last kx_profile_read: out[i*9 + 0..8] = GEMM rows, Cin, taps, dilation,
- * stride, store form, summed columns, FLOPs, milliseconds.  out = NULL returns the count only. */
+/* Per-launch records of the last kx_profile_read: out[i*10 + 0..9] = GEMM rows, Cin, taps, dilation,
+ * stride, store form, summed columns, FLOPs, milliseconds, algorithmic HBM bytes (input once + residual /
+ * running sum where read + output once + weights once).  out = NULL returns the count only. */
 int kx_profile_detail(kx_model* m, double* out, int64_t cap_rows, int64_t* n_rows);
+/* Unfused InstanceNorm statistics passes (in_stats_kernel) since the last call: launches and the bytes they must read
+ * (each reads its tensor exactly once) - the known byte count the PMC tooling checks FETCH_SIZE against. */
+int kx_profile_aux(kx_model* m, int64_t* stats_launches, double* stats_bytes);
 
 /* ---- voice table on device + output packing -----------------------------
  * kx_set_voice_table uploads the table that `TTSKoko::load_voices` builds (kokorox/src/tts/koko.rs:1308-1334;

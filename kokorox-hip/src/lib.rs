@@ -65,6 +65,7 @@ extern "C" {
     fn kx_profile_enable(m: *mut KxModel, on: c_int) -> c_int;
     fn kx_profile_read(m: *mut KxModel, launches: *mut i64, total_ms: *mut f64, total_flops: *mut f64) -> c_int;
     fn kx_profile_detail(m: *mut KxModel, out: *mut f64, cap_rows: i64, n_rows: *mut i64) -> c_int;
+    fn kx_profile_aux(m: *mut KxModel, stats_launches: *mut i64, stats_bytes: *mut f64) -> c_int;
     fn kx_set_voice_table(m: *mut KxModel, table: *const f32, n_voices: c_int) -> c_int;
     fn kx_infer_voices(m: *mut KxModel, ids: *const i64, t_stride: i64, lens: *const i32, b: c_int,
                        voice_ids: *const i32, weights: *const f32, max_mix: c_int, speeds: *const f32,
@@ -320,6 +321,12 @@ impl HipKoko {
         let (mut n, mut ms, mut fl) = (0i64, 0f64, 0f64);
         self.check(unsafe { kx_profile_read(self.h, &mut n, &mut ms, &mut fl) })?;
         Ok((n, ms, fl))
+    }
+    /// (launches, bytes) of the unfused InstanceNorm statistics passes since the last call.
+    pub fn profile_aux(&self) -> Result<(i64, f64), Box<dyn Error>> {
+        let (mut n, mut by) = (0i64, 0f64);
+        self.check(unsafe { kx_profile_aux(self.h, &mut n, &mut by) })?;
+        Ok((n, by))
     }
     /// Per-launch rows of the last `profile_read`: [rows, Cin, taps, dil, stride, store, cols, flops, ms, bytes].
     pub fn profile_detail(&self) -> Result<Vec<[f64; 10]>, Box<dyn Error>> {

@@ -322,10 +322,17 @@ int kx_profile_detail(kx_model* m, double* out, int64_t cap_rows, int64_t* n_row
         int64_t n = *n_rows < cap_rows ? *n_rows : cap_rows;
         for (int64_t i = 0; i < n; ++i) {
             const auto& r = M.prof_detail[i];
-            double* o = out + i * 9;
+            double* o = out + i * 10;
             o[0] = r.rows; o[1] = r.Cin; o[2] = r.K; o[3] = r.dil; o[4] = r.stride; o[5] = r.store;
-            o[6] = r.cols; o[7] = r.flops; o[8] = r.ms;
+            o[6] = r.cols; o[7] = r.flops; o[8] = r.ms; o[9] = r.bytes;
         }
+    });
+}
+
+int kx_profile_aux(kx_model* m, int64_t* stats_launches, double* stats_bytes) {
+    return guarded(m, [&](Model& M) {
+        KX_REQUIRE(stats_launches && stats_bytes, "profile_aux: null argument");
+        M.profile_aux(stats_launches, stats_bytes);
     });
 }
 

@@ -121,7 +121,8 @@ class Model {
     void set_pinned(const int32_t* pattern, int n);
     void profile_enable(bool on);
     void profile_read(int64_t* launches, double* ms, double* flops);
-    struct ProfRec { int rows, Cin, K, dil, stride, store; double cols, flops; float ms; };
+    struct ProfRec { int rows, Cin, K, dil, stride, store; double cols, flops; float ms; double bytes; };
+    void profile_aux(int64_t* stats_launches, double* stats_bytes);  // unfused InstanceNorm statistics passes since the last read
     std::vector<ProfRec> prof_detail;  // filled by profile_read (one record per timed launch)
     const Tap* find_tap(const std::string& name) const;
 
@@ -201,6 +202,8 @@ class Model {
     double prof_flops_ = 0.0;
     std::vector<ProfRec> prof_recs_;
     int64_t prof_launches_ = 0;
+    int64_t prof_stats_launches_ = 0;
+    double prof_stats_bytes_ = 0.0;
 };
 
 }  // namespace kx

@@ -467,7 +467,19 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
         for (int b = 0; b < B_; ++b) cols += (double)hl[b] * lm.mul + lm.add + (o.store == ST_UPSCATTER ? 1 : 0);
         prof_flops_ += 2.0 * w.rows * w.Cin * w.K * cols;
         prof_launches_ += 1;
-        prof_recs_.push_back(ProfRec{w.rows, w.Cin, w.K, o.dil, o.stride, o.store, cols, 2.0 * w.rows * w.Cin * w.K * cols, 0.f});
+        // algorithmic HBM bytes of the launch: the input tensor once, the residual and the running
+        // sum where the epilogue reads them, the output once, the split-f16 weights once
+        double in_cols = 0;
+        {
+            const std::vector<int>& hi = (in.len.lens == dT_) ? hT_ : hF_;
+            for (int b = 0; b < B_; ++b) in_cols += (double)hi[b] * in.len.mul + in.len.add;
+        }
+        const double out_rows = (o.store == ST_UPSCATTER) ? (double)(w.up_cout ? w.up_cout : 1) : (double)w.rows;
+        const double out_cols = (o.store == ST_UPSCATTER) ? cols * w.up_s : cols;
+        const double out_elems = out_rows * out_cols;
+        const double bytes = 4.0 * ((double)w.Cin * in_cols + out_elems * (1.0 + (o.resid ? 1.0 : 0.0) + (o.accum ? 1.0 : 0.0)) +
+                                    (double)w.rows * w.Cin * w.K);
+        prof_recs_.push_back(ProfRec{w.rows, w.Cin, w.K, o.dil, o.stride, o.store, cols, 2.0 * w.rows * w.Cin * w.K * cols, 0.f, bytes});
         if (ev_used_ + 2 > ev_.size()) {
             for (int i = 0; i < 64; ++i) {
                 hipEvent_t e;
@@ -507,6 +519,13 @@ void Model::stats(const T& x, const std::string& fc_key) {
         launch_stats_finalize(pi.part, pi.tiles, pi.cols_per_tile, x.C, x.len, B_, gb_ + fc_off(fc_key), gb_total_,
                               nmean_, nscale_, nshift_, n_bs_, stream_);
         return;
+    }
+    if (prof_on_) {  // (the PMC tooling checks FETCH_SIZE of this kernel against these bytes: it reads x exactly once)
+        const std::vector<int>& hl = (x.len.lens == dT_) ? hT_ : hF_;
+        double cols = 0;
+        for (int b = 0; b < B_; ++b) cols += (double)hl[b] * x.len.mul + x.len.add;
+        prof_stats_bytes_ += 4.0 * x.C * cols;
+        prof_stats_launches_ += 1;
     }
     launch_in_stats(x.p, x.bs, x.ld, x.C, x.len, B_, gb_ + fc_off(fc_key), gb_total_, nmean_, nscale_, nshift_, n_bs_,
                     raw, stream_);
@@ -660,6 +679,16 @@ void Model::profile_enable(bool on) {
     ev_used_ = 0;
     prof_flops_ = 0;
     prof_launches_ = 0;
+    prof_stats_bytes_ = 0;
+    prof_stats_launches_ = 0;
+}
+
+void Model::profile_aux(int64_t* stats_launches, double* stats_bytes) {
+    if (!prof_on_) throw Error(4, "profiling is not enabled");
+    *stats_launches = prof_stats_launches_;
+    *stats_bytes = prof_stats_bytes_;
+    prof_stats_launches_ = 0;
+    prof_stats_bytes_ = 0;
 }
 
 void Model::profile_read(int64_t* launches, double* ms, double* flops) {

@@ -87,6 +87,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_profile_enable": (i32, [vp, i32]),
         "kx_profile_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "kx_profile_detail": (i32, [vp, vp, i64, C.POINTER(i64)]),
+        "kx_profile_aux": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double)]),
         "kx_set_voice_table": (i32, [vp, vp, i32]),
         "kx_infer_voices": (i32, [vp, vp, i64, vp, i32, vp, vp, i32, vp, i32, u64, u32, i32, C.POINTER(vp), vp, vp]),
         "kx_infer_packed": (i32, [vp, vp, i64, vp, i32, vp, vp, i32, u64, u32, i32, C.POINTER(vp), vp, vp]),
@@ -118,7 +119,7 @@ ABI_SYMBOLS = [
     "kx_last_error", "kx_last_error_copy", "kx_infer",
     "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_set_utterance_base",
     "kx_set_conv_mode", "kx_get_conv_mode", "kx_set_stft_variant", "kx_get_stft_variant",
-    "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_set_voice_table", "kx_infer_voices",
+    "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_profile_aux", "kx_set_voice_table", "kx_infer_voices",
     "kx_infer_packed", "kx_free_packed", "kx_dispatcher_create", "kx_dispatcher_submit",
     "kx_dispatcher_stats", "kx_dispatcher_destroy", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test_attention", "kx_test_conv1d_epilogue",
 ]
@@ -329,12 +330,18 @@ class HipKoko:
         return int(n.value), float(ms.value), float(fl.value)
 
     def profile_detail(self) -> np.ndarray:
-        """[n, 9] rows of the last profile_read: rows, Cin, taps, dil, stride, store, cols, flops, ms."""
+        """[n, 10] rows of the last profile_read: rows, Cin, taps, dil, stride, store, cols, flops, ms, algorithmic bytes."""
         n = C.c_int64(0)
         self._check(self._lib.kx_profile_detail(self._h, None, 0, C.byref(n)))
-        out = np.zeros((max(n.value, 1), 9), dtype=np.float64)
+        out = np.zeros((max(n.value, 1), 10), dtype=np.float64)
         self._check(self._lib.kx_profile_detail(self._h, _ptr(out), n.value, C.byref(n)))
         return out[: n.value]
+
+    def profile_aux(self):
+        """(launches, bytes) of the unfused InstanceNorm statistics passes since the last call."""
+        n, by = C.c_int64(0), C.c_double(0)
+        self._check(self._lib.kx_profile_aux(self._h, C.byref(n), C.byref(by)))
+        return int(n.value), float(by.value)
 
     def tap(self, name: str, b: int = 0) -> np.ndarray:
         c, l = C.c_int32(0), C.c_int32(0)

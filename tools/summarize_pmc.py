@@ -1,14 +1,20 @@
-"""Summarise the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) for the dominant kernel.
+"""Summarise the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) for the dominant kernel family.
 
-Units/corrections follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: counters are in KiB; on gfx950
-FETCH_SIZE reports half of the bytes of a coalesced streaming read.  That factor is re-calibrated here
-on in_stats_kernel, which reads each activation tensor exactly once with the same 4-byte-per-lane
-coalesced pattern as the conv kernel's input staging (known bytes passed on the command line)."""
+Units/corrections follow /opt/skills/guides/MI355X_MICROARCH.md §HBM exactly: the counters are in KiB; on gfx950
+FETCH_SIZE reports HALF of the bytes of a wide coalesced streaming read, so it is doubled; WRITE_SIZE is taken as is.
+No hand-fed constants: the doubling is CHECKED (not calibrated) on in_stats_kernel, which reads each tensor it
+normalises exactly once - the bytes it must read come from the library's own launch accounting (bench.py prints them as
+"in_stats" in its JSON line, which the FETCH_SIZE pass keeps as its stdout).
+
+usage: summarize_pmc.py <fetch_dir> <write_dir> <out.json> <bench stdout of the FETCH pass> <kernel family substring> <mode>
+"""
 import collections
 import csv
 import glob
 import json
 import sys
+
+FETCH_FACTOR = 2.0  # MI355X_MICROARCH.md, HBM: FETCH_SIZE = TCC_EA0_RDREQ x 64 B with 128-B requests tallied at 64 B
 
 
 def load(pat):
@@ -19,27 +25,38 @@ def load(pat):
     return agg
 
 
-def main(fetch_dir, write_dir, out, stats_known_bytes_per_step, family="conv1d_mfma_kernel<128, 128, 2, 2>", mode="f32"):
+def main(fetch_dir, write_dir, out, bench_stdout, family="conv1d_f16x3_kernel<128,", mode="f16x3"):
     f = load(fetch_dir + "/*/*_counter_collection.csv")
     w = load(write_dir + "/*/*_counter_collection.csv")
     fam = [k for k in f if family in k]  # every instance of the BM=128 family counts as the dominant kernel
-    conv = family + (" (family, %d instances)" % len(fam) if len(fam) > 1 else "")
-    f[conv] = [sum(f[k][0] for k in fam), sum(f[k][1] for k in fam)]
-    w[conv] = [sum(w[k][0] for k in fam), sum(w[k][1] for k in fam)]
-    st = [k for k in f if "in_stats_kernel" in k][0]
-    calib = float(stats_known_bytes_per_step) / (f[st][1] * 1024)
-    n = f[conv][0]
+    n = sum(f[k][0] for k in fam)
+    fetch_kib = sum(f[k][1] for k in fam)
+    write_kib = sum(w[k][1] for k in fam)
+    bench = json.loads([l for l in open(bench_stdout).read().splitlines() if l.startswith("{")][-1])
+    steps = max(int(bench.get("steps", 1)) + int(bench.get("warmup", 0)), 1)  # every step of the run is counted
+    st = [k for k in f if "in_stats_kernel" in k]
+    check = None
+    if st and bench.get("in_stats"):
+        got = sum(f[k][1] for k in st) * 1024 * FETCH_FACTOR
+        want = bench["in_stats"]["bytes_per_step"] * steps
+        check = {"kernel": "in_stats_kernel", "launches": sum(f[k][0] for k in st),
+                 "bytes_it_must_read": want, "FETCH_SIZE_x2_bytes": got, "ratio": got / want if want else None,
+                 "note": "a CHECK of the x2 rule on a kernel with a known byte count (each tensor read exactly once, 4 B per "
+                         "lane coalesced); it is not used to rescale anything"}
+    alg = bench["roofline"].get("algorithmic_bytes_per_launch")
     res = {
-        "kernel": conv, "launches": n,
-        "FETCH_SIZE_KiB_per_launch": f[conv][1] / n, "WRITE_SIZE_KiB_per_launch": w[conv][1] / n,
-        "fetch_calibration_factor": calib,
-        "calibration": f"in_stats_kernel: {f[st][0]} launches, known {float(stats_known_bytes_per_step) / 1e9:.1f} GB read "
-                       f"per step vs FETCH_SIZE {f[st][1] * 1024 / 1e9:.1f} GB",
-        "fetch_bytes_per_launch_corrected": f[conv][1] / n * 1024 * round(calib),
-        "write_bytes_per_launch": w[conv][1] / n * 1024,
+        "kernel": family + f" (family, {len(fam)} instances)", "launches": n,
+        "FETCH_SIZE_KiB_per_launch": fetch_kib / n, "WRITE_SIZE_KiB_per_launch": write_kib / n,
+        "fetch_factor": FETCH_FACTOR,
+        "fetch_bytes_per_launch": fetch_kib / n * 1024 * FETCH_FACTOR,
+        "write_bytes_per_launch": write_kib / n * 1024,
+        "x2_rule_check": check,
+        "algorithmic_bytes_per_launch": alg,
     }
-    res["traffic_bytes_per_launch"] = res["fetch_bytes_per_launch_corrected"] + res["write_bytes_per_launch"]
-    res["workload"] = {"batch": 64, "tokens": 130, "frames": 422, "conv_mode": mode}
+    res["traffic_bytes_per_launch"] = res["fetch_bytes_per_launch"] + res["write_bytes_per_launch"]
+    res["traffic_over_algorithmic"] = res["traffic_bytes_per_launch"] / alg if alg else None
+    res["workload"] = {"batch": bench["config"]["batch_per_gpu"], "tokens": bench["config"]["tokens"],
+                       "frames": bench["config"]["frames"], "conv_mode": mode}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
