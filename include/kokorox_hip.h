@@ -155,6 +155,20 @@ int kx_profile_detail(kx_model* m, double* out, int64_t cap_rows, int64_t* n_row
  * (each reads its tensor exactly once) - the known byte count the PMC tooling checks FETCH_SIZE against. */
 int kx_profile_aux(kx_model* m, int64_t* stats_launches, double* stats_bytes);
 
+/* ---- real-weights readiness (tools/real_weights_report.py) -------------------------------------------------
+ * The f16x3 contraction carries every f32 operand as two f16 halves.  That is f32-class for O(1) activations; an input
+ * whose magnitude is far below 1e-3 loses its low half to the f16 subnormal quantum, one above 65504 is clamped.
+ * kx_diag_enable(1) makes every conv launch of the following kx_infer* calls also measure its input after the AdaIN
+ * affine (absmax, rms); kx_diag_count / kx_diag_get read the records (vals7 = GEMM rows, Cin, taps, current
+ * pre-scale exponent, absmax, rms, elements).  kx_set_act_prescale(name, e) multiplies that layer's transformed input
+ * by 2^e before the split and divides the accumulators by it in the epilogue - exact, so results are unchanged
+ * wherever the split was already lossless.  Layer names are the weight names without ".weight" (LSTM input
+ * projections: "<lstm>.ih"). */
+int kx_diag_enable(kx_model* m, int on);
+int kx_diag_count(kx_model* m, int64_t* n);
+int kx_diag_get(kx_model* m, int64_t i, char* name, size_t name_len, double* vals7);
+int kx_set_act_prescale(kx_model* m, const char* conv_name, int log2_scale);
+
 /* ---- voice table on device + output packing -----------------------------
  * kx_set_voice_table uploads the table that `TTSKoko::load_voices` builds (kokorox/src/tts/koko.rs:1308-1334;
  * layout [n_voices][511][1][256] f32, row 510 zero, kokorox/src/utils/hf_cache.rs:284-309) once; requests then

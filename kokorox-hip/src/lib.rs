@@ -66,6 +66,10 @@ extern "C" {
     fn kx_profile_read(m: *mut KxModel, launches: *mut i64, total_ms: *mut f64, total_flops: *mut f64) -> c_int;
     fn kx_profile_detail(m: *mut KxModel, out: *mut f64, cap_rows: i64, n_rows: *mut i64) -> c_int;
     fn kx_profile_aux(m: *mut KxModel, stats_launches: *mut i64, stats_bytes: *mut f64) -> c_int;
+    fn kx_diag_enable(m: *mut KxModel, on: c_int) -> c_int;
+    fn kx_diag_count(m: *mut KxModel, n: *mut i64) -> c_int;
+    fn kx_diag_get(m: *mut KxModel, i: i64, name: *mut c_char, name_len: usize, vals7: *mut f64) -> c_int;
+    fn kx_set_act_prescale(m: *mut KxModel, conv_name: *const c_char, log2_scale: c_int) -> c_int;
     fn kx_set_voice_table(m: *mut KxModel, table: *const f32, n_voices: c_int) -> c_int;
     fn kx_infer_voices(m: *mut KxModel, ids: *const i64, t_stride: i64, lens: *const i32, b: c_int,
                        voice_ids: *const i32, weights: *const f32, max_mix: c_int, speeds: *const f32,
@@ -312,6 +316,28 @@ impl HipKoko {
     }
     pub fn set_utterance_base(&self, base: u64) -> Result<(), Box<dyn Error>> {
         self.check(unsafe { kx_set_utterance_base(self.h, base) })
+    }
+    /// Real-weights diagnostics: measure every conv input during the following calls.
+    pub fn diag_enable(&self, on: bool) -> Result<(), Box<dyn Error>> {
+        self.check(unsafe { kx_diag_enable(self.h, on as c_int) })
+    }
+    /// (layer, [rows, Cin, taps, pre-scale exponent, absmax, rms, elements]) per conv launch since `diag_enable(true)`.
+    pub fn diag_records(&self) -> Result<Vec<(String, [f64; 7])>, Box<dyn Error>> {
+        let mut n = 0i64;
+        self.check(unsafe { kx_diag_count(self.h, &mut n) })?;
+        let mut out = Vec::with_capacity(n as usize);
+        for i in 0..n {
+            let mut name = vec![0 as c_char; 128];
+            let mut v = [0f64; 7];
+            self.check(unsafe { kx_diag_get(self.h, i, name.as_mut_ptr(), name.len(), v.as_mut_ptr()) })?;
+            out.push((cstr_buf(&name), v));
+        }
+        Ok(out)
+    }
+    /// f16x3: multiply a layer's transformed input by 2^log2_scale before the hi/lo split (undone exactly).
+    pub fn set_act_prescale(&self, layer: &str, log2_scale: i32) -> Result<(), Box<dyn Error>> {
+        let c = CString::new(layer)?;
+        self.check(unsafe { kx_set_act_prescale(self.h, c.as_ptr(), log2_scale) })
     }
     pub fn profile_enable(&self, on: bool) -> Result<(), Box<dyn Error>> {
         self.check(unsafe { kx_profile_enable(self.h, on as c_int) })

@@ -336,6 +336,35 @@ int kx_profile_aux(kx_model* m, int64_t* stats_launches, double* stats_bytes) {
     });
 }
 
+int kx_diag_enable(kx_model* m, int on) {
+    return guarded(m, [&](Model& M) { M.diag_enable(on != 0); });
+}
+
+int kx_diag_count(kx_model* m, int64_t* n) {
+    return guarded(m, [&](Model& M) {
+        KX_REQUIRE(n, "diag_count: null argument");
+        *n = (int64_t)M.diag_collect().size();
+    });
+}
+
+int kx_diag_get(kx_model* m, int64_t i, char* name, size_t name_len, double* vals7) {
+    return guarded(m, [&](Model& M) {
+        KX_REQUIRE(name && name_len && vals7, "diag_get: null argument");
+        const auto& d = M.diag_collect();
+        KX_REQUIRE(i >= 0 && i < (int64_t)d.size(), "diag_get: index out of range");
+        set_err(name, name_len, d[i].name);
+        vals7[0] = d[i].rows; vals7[1] = d[i].Cin; vals7[2] = d[i].K; vals7[3] = d[i].act_shift;
+        vals7[4] = d[i].absmax; vals7[5] = d[i].rms; vals7[6] = d[i].count;
+    });
+}
+
+int kx_set_act_prescale(kx_model* m, const char* conv_name, int log2_scale) {
+    return guarded(m, [&](Model& M) {
+        KX_REQUIRE(conv_name, "set_act_prescale: null argument");
+        M.set_act_shift(conv_name, log2_scale);
+    });
+}
+
 int kx_debug_tap(kx_model* m, const char* name, int b, float* out, int64_t out_cap, int32_t* C, int32_t* L) {
     return guarded(m, [&](Model& M) {
         KX_REQUIRE(name && C && L, "debug_tap: null argument");
@@ -475,6 +504,7 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
             a.w16 = p16;
             a.n_chunks16 = (Cin + 15) / 16;
             a.w_unscale = std::ldexp(1.0f, -ws);
+            a.x_prescale = 1.0f;
             kx::launch_conv1d_f16x3(a, BM, B, transposed ? L + 1 : Lout, nullptr);
         } else {
             kx::launch_conv1d(a, BM, B, transposed ? L + 1 : Lout, nullptr);

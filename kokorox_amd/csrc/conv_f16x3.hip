@@ -165,7 +165,7 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
     // transform one column's 8 channels and write its two 16-byte slots
     auto emit8 = [&](int vt, int ch, int u, const float (&x8)[8], const Oct& o, bool pok) {
         unsigned hp[4], lp[4];
-        const float keep = pok ? 1.f : 0.f;
+        const float keep = pok ? a.x_prescale : 0.f;  // (zero padding and the activation pre-scale in one multiply)
 #pragma unroll
         for (int c2 = 0; c2 < 4; ++c2) {
             float y2[2];

@@ -133,7 +133,7 @@ void conv1d_f16x3_ws_kernel(const ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int p = p0 + lane + 64 * j;
-                keep[j] = (p >= 0 && p < Lin) ? 1.f : 0.f;
+                keep[j] = (p >= 0 && p < Lin) ? a.x_prescale : 0.f;  // (zero padding and the activation pre-scale)
                 int pi = up2 ? (p >> 1) : p;
                 pi = pi < 0 ? 0 : (pi >= Lsrc ? Lsrc - 1 : pi);
                 xoff[j] = 4u * (unsigned)pi;

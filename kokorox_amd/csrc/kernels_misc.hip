@@ -426,6 +426,37 @@ void launch_pack_audio(const float* audio, long audio_ld, const int* frames, int
     KX_HIP(hipGetLastError());
 }
 
+// ---- diagnostics: magnitude of a conv input after its AdaIN affine ---------------------------------------------
+__global__ void diag_stats_kernel(const float* x, long bs, int ld, int C, LenMap len, const float* nmean,
+                                  const float* nscale, const float* nshift, int n_bs, float* out3) {
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int L = len_of(len, b);
+    const float m = nmean ? nmean[(long)b * n_bs + c] : 0.f, sc = nscale ? nscale[(long)b * n_bs + c] : 1.f,
+                h = nshift ? nshift[(long)b * n_bs + c] : 0.f;
+    const float* row = x + b * bs + (long)c * ld;
+    float amax = 0.f, sq = 0.f;
+    for (int t = threadIdx.x; t < L; t += blockDim.x) {
+        const float y = (row[t] - m) * sc + h;
+        amax = fmaxf(amax, fabsf(y));
+        sq += y * y;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        amax = fmaxf(amax, __shfl_down(amax, o));
+        sq += __shfl_down(sq, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(reinterpret_cast<unsigned*>(out3), __float_as_uint(amax));  // non-negative floats order as uints
+        atomicAdd(out3 + 1, sq);
+        if (threadIdx.x == 0) atomicAdd(out3 + 2, (float)L);
+    }
+}
+void launch_diag_stats(const float* x, long bs, int ld, int C, LenMap len, int B, int Lmax, const float* nmean,
+                       const float* nscale, const float* nshift, int n_bs, float* out3, hipStream_t s) {
+    (void)Lmax;
+    hipLaunchKernelGGL(diag_stats_kernel, dim3(C, B), dim3(256), 0, s, x, bs, ld, C, len, nmean, nscale, nshift, n_bs, out3);
+    KX_HIP(hipGetLastError());
+}
+
 // ---- row fills / copies ---------------------------------------------------------------------
 __global__ void fill_style_rows_kernel(float* dst, long bs, int ld, int row0, const float* styles, int style_off,
                                        const int* lens) {

@@ -82,6 +82,8 @@ struct ConvArgs {
     const void* w16;
     int n_chunks16;
     float w_unscale;
+    float x_prescale;  // f16x3: power of two applied to the transformed input before the hi/lo split (w_unscale carries
+                       // its inverse); 1 unless a layer's activations are so small that their low halves would be lost
     // k = 1 GEMMs over a short axis: columns of all B utterances form one merged space of B * merge_T
     // columns (utterance = col / merge_T); 0 = off.  Requires K = 1, stride 1, pad 0, no norm, no in_up2.
     int merge_T;
@@ -163,6 +165,11 @@ void launch_stats_finalize(const float2* part, int tiles, int cols_per_tile, int
                            long gb_bs, float* mean, float* scale, float* shift, int n_bs, hipStream_t s);
 void launch_in_stats(const float* x, long bs, int ld, int C, LenMap len, int B, const float* gb, long gb_bs,
                      float* mean, float* scale, float* shift, int n_bs, float2* raw_out, hipStream_t s);
+
+// diagnostics (real-weights report): absmax and sum of squares of a conv's input after its AdaIN affine
+// (out[0] = absmax bits as uint, out[1] = sum of squares, out[2] = element count)
+void launch_diag_stats(const float* x, long bs, int ld, int C, LenMap len, int B, int Lmax, const float* nmean,
+                       const float* nscale, const float* nshift, int n_bs, float* out3, hipStream_t s);
 
 void launch_style_mix(const float* table, int n_voices, const int* voice_ids, const float* weights, int max_mix,
                       const int* rows, float* styles, int B, hipStream_t s);

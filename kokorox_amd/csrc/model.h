@@ -23,6 +23,8 @@ struct ConvW {
     const void* w16 = nullptr;  // split-f16 image (conv_f16x3.hip)
     int n_chunks16 = 0;
     float unscale = 1.f;        // 2^-ws
+    std::string name;           // registry key (diagnostics, kx_set_act_prescale)
+    int act_shift = 0;          // f16x3: the transformed input is multiplied by 2^act_shift before the hi/lo split
 };
 
 struct LstmW {
@@ -124,6 +126,12 @@ class Model {
     struct ProfRec { int rows, Cin, K, dil, stride, store; double cols, flops; float ms; double bytes; };
     void profile_aux(int64_t* stats_launches, double* stats_bytes);  // unfused InstanceNorm statistics passes since the last read
     std::vector<ProfRec> prof_detail;  // filled by profile_read (one record per timed launch)
+    // real-weights diagnostics: with diag on, every conv launch also measures its input (after the AdaIN affine)
+    struct DiagRec { std::string name; int rows, Cin, K, act_shift; double absmax, rms, count; };
+    void diag_enable(bool on);
+    const std::vector<DiagRec>& diag_collect();  // syncs, converts the device slots of the last call(s)
+    void set_act_shift(const std::string& conv_name, int shift);
+    int get_act_shift(const std::string& conv_name) const;
     const Tap* find_tap(const std::string& name) const;
 
     std::mutex mu;
@@ -196,6 +204,10 @@ class Model {
     struct PartInfo { const float2* part; int tiles, cols_per_tile, C; };
     std::map<const float*, PartInfo> parts_;  // output tensor -> fused statistics partials of its producer
 
+    bool diag_on_ = false;
+    std::vector<DiagRec> diag_recs_;
+    float* d_diag_ = nullptr;  // [diag_cap_][3]
+    size_t diag_cap_ = 0, diag_used_ = 0;
     bool prof_on_ = false;
     std::vector<hipEvent_t> ev_;
     size_t ev_used_ = 0;

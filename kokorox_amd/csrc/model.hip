@@ -349,6 +349,8 @@ void Model::build() {
     for (int i = 0; i < 6; ++i) reg_resblock1(G + "resblocks." + std::to_string(i));
     convs_[G + "conv_post"] = make_conv(G + "conv_post");
 
+    for (auto& kv : convs_) kv.second.name = kv.first;
+    for (auto& kv : lstms_) kv.second.ih.name = kv.first + ".ih";
     KX_HIP(hipMalloc((void**)&fc_dev_, fc_host_.size() * sizeof(FcDesc)));
     owned_.push_back(fc_dev_);
     KX_HIP(hipMemcpyAsync(fc_dev_, fc_host_.data(), fc_host_.size() * sizeof(FcDesc), hipMemcpyHostToDevice, stream_));
@@ -420,7 +422,13 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     const bool f16 = conv_mode == CONV_F16X3;
     a.w16 = w.w16;
     a.n_chunks16 = w.n_chunks16;
-    a.w_unscale = w.unscale;
+    a.x_prescale = std::ldexp(1.0f, w.act_shift);
+    a.w_unscale = std::ldexp(w.unscale, -w.act_shift);  // (exact: both are powers of two)
+    if (diag_on_ && diag_used_ < diag_cap_) {
+        float* slot = d_diag_ + 3 * diag_used_++;
+        launch_diag_stats(in.p, in.bs, in.ld, w.Cin, in.len, B_, in.Lmax, o.nmean, o.nscale, o.nshift, n_bs_, slot, stream_);
+        diag_recs_.push_back(DiagRec{w.name, w.rows, w.Cin, w.K, w.act_shift, 0.0, 0.0, 0.0});
+    }
     parts_.erase(out.p);  // whatever statistics were known for this tensor are stale now
     static const bool fuse_stats = !(getenv("KX_FUSE_STATS") && atoi(getenv("KX_FUSE_STATS")) == 0);
     if (fuse_stats && o.stat_part && o.store == ST_NORMAL && !o.accum) {
@@ -670,6 +678,55 @@ void Model::set_pinned(const int32_t* pattern, int n) {
     }
     KX_HIP(hipMemcpy(d_pinned_, pattern, n * sizeof(int), hipMemcpyHostToDevice));
     n_pinned_ = n;
+}
+
+void Model::diag_enable(bool on) {
+    sync();
+    diag_on_ = on;
+    diag_recs_.clear();
+    diag_used_ = 0;
+    if (on && !d_diag_) {
+        diag_cap_ = 1024;
+        d_diag_ = dev_alloc(3 * diag_cap_);
+    }
+    if (on) KX_HIP(hipMemset(d_diag_, 0, 3 * diag_cap_ * sizeof(float)));
+}
+
+const std::vector<Model::DiagRec>& Model::diag_collect() {
+    sync();
+    std::vector<float> h(3 * diag_used_);
+    if (diag_used_) KX_HIP(hipMemcpy(h.data(), d_diag_, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < diag_recs_.size() && i < diag_used_; ++i) {
+        diag_recs_[i].absmax = h[3 * i];
+        diag_recs_[i].count = (double)h[3 * i + 2];  // (one add of the utterance's length per channel and utterance)
+        diag_recs_[i].rms = diag_recs_[i].count > 0 ? std::sqrt((double)h[3 * i + 1] / diag_recs_[i].count) : 0.0;
+    }
+    return diag_recs_;
+}
+
+void Model::set_act_shift(const std::string& conv_name, int shift) {
+    KX_REQUIRE(shift >= -24 && shift <= 24, "activation pre-scale: shift must be in -24..24");
+    sync();
+    auto it = convs_.find(conv_name);
+    if (it != convs_.end()) {
+        it->second.act_shift = shift;
+        return;
+    }
+    const std::string suf = ".ih";
+    if (conv_name.size() > suf.size() && conv_name.compare(conv_name.size() - suf.size(), suf.size(), suf) == 0) {
+        auto il = lstms_.find(conv_name.substr(0, conv_name.size() - suf.size()));
+        if (il != lstms_.end()) {
+            il->second.ih.act_shift = shift;
+            return;
+        }
+    }
+    throw Error(4, "no such conv layer: " + conv_name);
+}
+
+int Model::get_act_shift(const std::string& conv_name) const {
+    auto it = convs_.find(conv_name);
+    if (it == convs_.end()) throw Error(4, "no such conv layer: " + conv_name);
+    return it->second.act_shift;
 }
 
 void Model::profile_enable(bool on) {

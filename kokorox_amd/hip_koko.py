@@ -88,6 +88,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_profile_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "kx_profile_detail": (i32, [vp, vp, i64, C.POINTER(i64)]),
         "kx_profile_aux": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double)]),
+        "kx_diag_enable": (i32, [vp, i32]),
+        "kx_diag_count": (i32, [vp, C.POINTER(i64)]),
+        "kx_diag_get": (i32, [vp, i64, cp, sz, vp]),
+        "kx_set_act_prescale": (i32, [vp, cp, i32]),
         "kx_set_voice_table": (i32, [vp, vp, i32]),
         "kx_infer_voices": (i32, [vp, vp, i64, vp, i32, vp, vp, i32, vp, i32, u64, u32, i32, C.POINTER(vp), vp, vp]),
         "kx_infer_packed": (i32, [vp, vp, i64, vp, i32, vp, vp, i32, u64, u32, i32, C.POINTER(vp), vp, vp]),
@@ -119,7 +123,7 @@ ABI_SYMBOLS = [
     "kx_last_error", "kx_last_error_copy", "kx_infer",
     "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_set_utterance_base",
     "kx_set_conv_mode", "kx_get_conv_mode", "kx_set_stft_variant", "kx_get_stft_variant",
-    "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_profile_aux", "kx_set_voice_table", "kx_infer_voices",
+    "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_profile_aux", "kx_diag_enable", "kx_diag_count", "kx_diag_get", "kx_set_act_prescale", "kx_set_voice_table", "kx_infer_voices",
     "kx_infer_packed", "kx_free_packed", "kx_dispatcher_create", "kx_dispatcher_submit",
     "kx_dispatcher_stats", "kx_dispatcher_destroy", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test_attention", "kx_test_conv1d_epilogue",
 ]
@@ -342,6 +346,26 @@ class HipKoko:
         n, by = C.c_int64(0), C.c_double(0)
         self._check(self._lib.kx_profile_aux(self._h, C.byref(n), C.byref(by)))
         return int(n.value), float(by.value)
+
+    def diag_enable(self, on: bool):
+        """Measure every conv input (after its AdaIN affine) during the following calls (real-weights report)."""
+        self._check(self._lib.kx_diag_enable(self._h, 1 if on else 0))
+
+    def diag_records(self):
+        """[(layer, rows, Cin, taps, pre-scale exponent, absmax, rms, elements)] since diag_enable(True)."""
+        n = C.c_int64(0)
+        self._check(self._lib.kx_diag_count(self._h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            name = C.create_string_buffer(128)
+            v = np.zeros(7, dtype=np.float64)
+            self._check(self._lib.kx_diag_get(self._h, i, name, len(name), _ptr(v)))
+            out.append((name.value.decode(), int(v[0]), int(v[1]), int(v[2]), int(v[3]), float(v[4]), float(v[5]), float(v[6])))
+        return out
+
+    def set_act_prescale(self, layer: str, log2_scale: int):
+        """f16x3: multiply this layer's transformed input by 2**log2_scale before the hi/lo split (undone exactly)."""
+        self._check(self._lib.kx_set_act_prescale(self._h, layer.encode(), log2_scale))
 
     def tap(self, name: str, b: int = 0) -> np.ndarray:
         c, l = C.c_int32(0), C.c_int32(0)

@@ -263,6 +263,45 @@ def test_last_error_is_a_per_thread_copy(hip_model):
     assert len(seen) == 60 and all("token id outside" in m for m in seen)
 
 
+def test_activation_prescale_and_diagnostics_cover_every_conv(hip_model):
+    """Real-weights kit.  A power-of-two activation pre-scale only moves the f16 subnormal quantum of the low halves
+    (2^-25 absolute): results change at the 1e-7..1e-6 level (the recurrences amplify it a little), never more (the waveform itself is not compared: it sits behind
+    the F0 -> phase edge).  The diagnostics see every conv launch with sane magnitudes on the synthetic
+    weights."""
+    from kokorox_amd import hip_koko as hk
+    ids, styles = _inputs([19], seed0=70)
+    taps = ["bert.out", "dur.lstm", "pred.shared", "text_enc.out", "dec.encode", "dec.decode.3"]
+    hip_model.infer([list(ids[0])], [list(styles[0])], 1.0, seed=5, flags=hk.KX_FLAG_TAPS)
+    ref = {t: hip_model.tap(t, 0) for t in taps + ["pred.F0"]}
+    layers = ["decoder.decode.1.conv2", "bert.ffn", "predictor.lstm.ih", "decoder.encode.conv1", "text_encoder.cnn.1",
+              "decoder.generator.resblocks.3.convs1.0", "decoder.generator.ups.1"]
+    try:
+        for e, name in zip((3, -2, 5, 1, 4, 2, 3), layers):
+            hip_model.set_act_prescale(name, e)
+        out = hip_model.infer([list(ids[0])], [list(styles[0])], 1.0, seed=5, flags=hk.KX_FLAG_TAPS)
+        got = {t: hip_model.tap(t, 0) for t in taps + ["pred.F0"]}
+    finally:
+        for name in layers:
+            hip_model.set_act_prescale(name, 0)
+    assert np.isfinite(out).all()
+    for t in taps:
+        assert np.abs(got[t] - ref[t]).max() <= 1e-5 * max(1.0, np.abs(ref[t]).max()), t
+    assert np.abs(got["pred.F0"] - ref["pred.F0"]).max() <= 2e-5 * np.abs(ref["pred.F0"]).max()
+    with pytest.raises(Exception, match="no such conv layer"):
+        hip_model.set_act_prescale("decoder.nonexistent", 1)
+    hip_model.diag_enable(True)
+    try:
+        hip_model.infer([list(ids[0])], [list(styles[0])], 1.0, seed=5)
+        recs = hip_model.diag_records()
+    finally:
+        hip_model.diag_enable(False)
+    names = {r[0] for r in recs}
+    assert len(recs) >= 150 and "decoder.generator.conv_post" in names and "bert.qkv" in names
+    for name, rows, cin, k, sh, amax, rms, cnt in recs:
+        assert np.isfinite(amax) and np.isfinite(rms) and cnt > 0, name
+        assert amax < 6e4 and (rms > 1e-3 or "F0_conv" in name or "N_conv" in name), (name, amax, rms)
+
+
 def test_max_length_utterance(hip_model):
     """510 tokens + 2 pads is the model limit (voice table rows, hf_cache.rs:302-309)."""
     from oracle import kokoro_ref as R
