@@ -593,7 +593,16 @@ int kx_test_lstm(int device_id, const float* x, int B, int L, int n_in, const fl
         a.up_cout = 1;
         kx::launch_conv1d(a, 128, B, L, nullptr);
         float* dy = dm.get<float>((size_t)B * 512 * L);
-        kx::launch_lstm(gx, (long)L * 2048, 2048, whhT, dy, (long)512 * L, L, kx::LenMap{d_len, 1, 0}, B, nullptr);
+        // (the hook runs the product's two-CU recurrence: exchange buffer + sticky error word as Model holds them)
+        unsigned long long* xchg = dm.get<unsigned long long>(kx::lstm_exchange_bytes(B) / sizeof(unsigned long long));
+        KX_HIP(hipMemset(xchg, 0, kx::lstm_exchange_bytes(B)));
+        unsigned* errw = dm.get<unsigned>(1);
+        KX_HIP(hipMemset(errw, 0, sizeof(unsigned)));
+        kx::launch_lstm(gx, (long)L * 2048, 2048, whhT, dy, (long)512 * L, L, kx::LenMap{d_len, 1, 0}, B, xchg, errw, nullptr);
+        KX_HIP(hipDeviceSynchronize());
+        unsigned herr = 0;
+        KX_HIP(hipMemcpy(&herr, errw, sizeof(unsigned), hipMemcpyDeviceToHost));
+        if (herr) throw Error(KX_ERR_DEVICE, "test_lstm: the two-CU recurrence timed out waiting for its partner");
         KX_HIP(hipDeviceSynchronize());
         std::vector<float> yc((size_t)B * 512 * L);
         KX_HIP(hipMemcpy(yc.data(), dy, yc.size() * 4, hipMemcpyDeviceToHost));

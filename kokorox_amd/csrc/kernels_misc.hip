@@ -6,6 +6,8 @@
 // work is in conv_mfma.hip.
 #include <cmath>
 
+#include <atomic>
+
 #include "kx_common.h"
 
 namespace kx {
@@ -564,9 +566,143 @@ __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gx_bs,
         __syncthreads();
     }
 }
+// ---- the same recurrence with W_hh fully resident: two CUs per (utterance, direction) -------------------------------
+// One CU cannot hold the 1 MiB of W_hh (512 KiB of registers + 160 KiB of LDS), which is why lstm_kernel streams 60 % of
+// it from L2 on every step (5.5 us per step, bound by the CU's L1 fill rate).  Here the recurrence of one (utterance,
+// direction) runs on TWO workgroups = two CUs.  Half hf owns hidden units [128 hf, 128 hf + 128) with all four of their
+// gate rows (512 rows x 256 k = 512 KiB: 96 registers per thread + 128 KiB of LDS), so it updates its own cells locally
+// and the only traffic per step is the exchange of the 128 new h values each way: 8-byte {h, tag} granules written with
+// one agent-scope (sc1) store each and polled with agent-scope loads - the data-tagged hand-off of
+// MI355X_MICROARCH.md ("R2 granule": a granule is valid when its tag is the expected step; no fence, no flag).
+// The tag carries a per-launch epoch, so the exchange buffer never needs clearing; two slots by step parity (a half
+// can only be one step ahead of its partner).  The two halves are adjacent blocks; blocks are dispatched in order, so
+// at most one pair per launch is ever waiting for a partner that is not resident yet.  Every poll is bounded: if the
+// partner never shows up the half raises the model's sticky error word and leaves (an error, never a hang).
+constexpr int LSTMP_REG = 24;           // float4 (4 k) pieces of a thread's 32 held in registers, the rest in LDS
+constexpr int LSTMP_LDS = 32 - LSTMP_REG;
+__global__ __launch_bounds__(1024) void lstm_pair_kernel(const float* gx, long gx_bs, int gx_ld, const float* whhT,
+                                                         float* y, long y_bs, int y_ld, LenMap len,
+                                                         unsigned long long* xchg, unsigned epoch, unsigned* err) {
+    extern __shared__ __attribute__((aligned(16))) float lstm_smem[];
+    float* hs = lstm_smem;                                   // [256] h of the previous step (both halves)
+    float* part = hs + 256;                                  // [512] partial sums of the upper k half
+    float* gates = part + 512;                               // [512] gate pre-activations of this half
+    int* abort_flag = reinterpret_cast<int*>(gates + 512);   // [4] (one word used): a poll timed out
+    float4* wl = reinterpret_cast<float4*>(gates + 512 + 4); // [LSTMP_LDS][1024] x 4 k: the tail of every thread's 128 k
+    const int hf = blockIdx.x & 1, pair = blockIdx.x >> 1;   // pair = b * 2 + dir
+    const int b = pair >> 1, dir = pair & 1, tid = threadIdx.x;
+    const int L = len_of(len, b);
+    const int rr = tid & 511, kh = tid >> 9;                 // local row (gate q = rr >> 7, unit rr & 127), k half
+    const int row = (rr >> 7) * 256 + hf * 128 + (rr & 127); // row of W_hh / column of gx
+    // image [k4][row][4 k] (launch_transpose_whh): k4 = kh * 32 + j covers this thread's 128 k
+    const float4* W4 = reinterpret_cast<const float4*>(whhT + (long)dir * 256 * 1024) + (long)kh * 32 * 1024 + row;
+    float4 wreg[LSTMP_REG];
+#pragma unroll
+    for (int j = 0; j < LSTMP_REG; ++j) wreg[j] = W4[(long)j * 1024];
+#pragma unroll
+    for (int j = 0; j < LSTMP_LDS; ++j) wl[j * 1024 + tid] = W4[(long)(LSTMP_REG + j) * 1024];
+    if (tid < 256) hs[tid] = 0.f;
+    if (tid == 0) *abort_flag = 0;
+    float c = 0.f;
+    // exchange slots: [pair][parity][half][128] granules
+    unsigned long long* mine = xchg + (((long)pair * 2) * 2 + hf) * 128;       // + parity * 256
+    unsigned long long* theirs = xchg + (((long)pair * 2) * 2 + (1 - hf)) * 128;
+    const float* gxp = gx + b * gx_bs + dir * 1024 + row;
+    float gxv = (kh == 0 && L > 0) ? gxp[(long)(dir ? L - 1 : 0) * gx_ld] : 0.f;
+    __syncthreads();
+    for (int step = 0; step < L; ++step) {
+        const int t = dir ? (L - 1 - step) : step;
+        const float4* h4 = reinterpret_cast<const float4*>(hs) + kh * 32;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < LSTMP_REG; ++j) {
+            const float4 hv = h4[j];
+            acc = fmaf(wreg[j].x, hv.x, acc);
+            acc = fmaf(wreg[j].y, hv.y, acc);
+            acc = fmaf(wreg[j].z, hv.z, acc);
+            acc = fmaf(wreg[j].w, hv.w, acc);
+        }
+#pragma unroll
+        for (int j = 0; j < LSTMP_LDS; ++j) {
+            const float4 hv = h4[LSTMP_REG + j];
+            const float4 w = wl[j * 1024 + tid];
+            acc = fmaf(w.x, hv.x, acc);
+            acc = fmaf(w.y, hv.y, acc);
+            acc = fmaf(w.z, hv.z, acc);
+            acc = fmaf(w.w, hv.w, acc);
+        }
+        if (kh) part[rr] = acc;
+        __syncthreads();
+        if (!kh) {
+            gates[rr] = (gxv + acc) + part[rr];
+            // the input projection of the next step (its latency hides behind the rest of this one)
+            if (step + 1 < L) gxv = gxp[(long)(dir ? t - 1 : t + 1) * gx_ld];
+        }
+        __syncthreads();
+        const unsigned tag = (epoch << 16) | (unsigned)(step + 1);
+        const int par = step & 1;
+        if (tid < 128) {
+            const float ig = 1.0f / (1.0f + expf(-gates[tid]));
+            const float fg = 1.0f / (1.0f + expf(-gates[128 + tid]));
+            const float gg = tanhf(gates[256 + tid]);
+            const float og = 1.0f / (1.0f + expf(-gates[384 + tid]));
+            c = fg * c + ig * gg;
+            const float hn = og * tanhf(c);
+            hs[hf * 128 + tid] = hn;
+            if (step + 1 < L) {  // publish for the partner's next step: one 8-byte agent-scope store
+                const unsigned long long g8 = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(hn);
+                __hip_atomic_store(mine + par * 256 + tid, g8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            y[b * y_bs + (long)(dir * 256 + hf * 128 + tid) * y_ld + t] = hn;
+        } else if (tid < 256 && step + 1 < L) {
+            // threads 128..255 fetch the partner's half: poll each granule until it carries this step's tag
+            const int j = tid - 128;
+            unsigned long long g8 = 0;
+            int spins = 0;
+            for (;;) {
+                g8 = __hip_atomic_load(theirs + par * 256 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(g8 >> 32) == tag) break;
+                if (++spins > (1 << 21)) {  // ~ seconds: the partner is not coming
+                    atomicOr(err, 2u);
+                    *abort_flag = 1;
+                    g8 = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            hs[(1 - hf) * 128 + j] = __uint_as_float((unsigned)(g8 & 0xffffffffu));
+        }
+        __syncthreads();
+        if (*abort_flag) return;  // (workgroup-uniform: written before the barrier above)
+    }
+}
+
+static bool lstm_use_pair() {
+    static const int v = getenv("KX_LSTM_PAIR") ? atoi(getenv("KX_LSTM_PAIR")) : 1;
+    return v != 0;
+}
+
+size_t lstm_exchange_bytes(int B) { return (size_t)B * 2 * 2 * 2 * 128 * sizeof(unsigned long long); }
+
 void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, float* y, long y_bs, int y_ld,
-                 LenMap len, int B, hipStream_t s) {
+                 LenMap len, int B, unsigned long long* xchg, unsigned* err_word, hipStream_t s) {
     static_assert(LSTM_LDS_K % 4 == 0 && LSTM_REG_K % 4 == 0, "whole float4 groups of h");
+    if (lstm_use_pair() && xchg && err_word) {
+        const size_t lds = sizeof(float) * (256 + 512 + 512 + 4 + (size_t)LSTMP_LDS * 1024 * 4);
+        static bool pair_attr = false;
+        if (!pair_attr) {
+            KX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_pair_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            pair_attr = true;
+        }
+        static std::atomic<unsigned> epoch_ctr{0};
+        unsigned epoch = (epoch_ctr.fetch_add(1) + 1) & 0xffffu;
+        if (epoch == 0) epoch = (epoch_ctr.fetch_add(1) + 1) & 0xffffu;  // (0 is what a fresh buffer holds)
+        hipLaunchKernelGGL(lstm_pair_kernel, dim3(B * 2 * 2), dim3(1024), lds, s, gx, gx_bs, gx_ld, whhT, y, y_bs, y_ld, len,
+                           xchg, epoch, err_word);
+        KX_HIP(hipGetLastError());
+        return;
+    }
     const size_t lds = sizeof(float) * (256 + 1024 + (size_t)LSTM_LDS_K * 1024);
     static bool attr_set = false;
     if (!attr_set) {

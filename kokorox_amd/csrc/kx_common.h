@@ -184,8 +184,11 @@ void launch_fill_style_rows(float* dst, long bs, int ld, int row0, const float* 
 void launch_copy_rows(const float* src, long sbs, int sld, float* dst, long dbs, int dld, int rows, LenMap len,
                       int B, int Lmax, hipStream_t s);
 
+// xchg / err_word: exchange buffer (lstm_exchange_bytes(B), any contents) and sticky error word of the two-CU form;
+// null = the one-CU streaming kernel
 void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, float* y, long y_bs, int y_ld,
-                 LenMap len, int B, hipStream_t s);
+                 LenMap len, int B, unsigned long long* xchg, unsigned* err_word, hipStream_t s);
+size_t lstm_exchange_bytes(int B);
 
 void launch_duration(const float* logits, long bs, int ld, const float* speeds, int n_speed, const int* lens,
                      const int* pinned, int n_pinned, int* dur, int* frames, int* idx, int idx_ld, int B,

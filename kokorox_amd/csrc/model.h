@@ -193,6 +193,13 @@ class Model {
     int B_ = 0, Tmax_ = 0, Fmax_ = 0;
     std::vector<int> hT_, hF_;
     int *dT_ = nullptr, *dF_ = nullptr;
+    // two-CU LSTM: exchange buffers (one for the main stream, one for the TextEncoder branch that runs beside it) and the
+    // sticky device error word (bit 1: a half never saw its partner) checked at every host synchronisation
+    unsigned long long* d_xchg_[2] = {nullptr, nullptr};
+    size_t xchg_cap_ = 0;
+    unsigned* d_dev_err_ = nullptr;
+    hipStream_t main_stream_ = nullptr;
+    void check_dev_err();
     unsigned* d_bad_id_ = nullptr;  // sticky word: first out-of-table token id seen by the embedding kernels
     float* gb_ = nullptr;  // [B][gb_total_]
     float *nmean_ = nullptr, *nscale_ = nullptr, *nshift_ = nullptr;

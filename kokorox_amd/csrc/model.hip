@@ -18,6 +18,9 @@ Model::Model(int dev) : device(dev) {
     if (const char* e = getenv("KOKOROX_STFT")) stft_variant = (strcmp(e, "torch") == 0) ? STFT_TORCH : STFT_ONNX;
     KX_HIP(hipSetDevice(device));
     KX_HIP(hipStreamCreate(&stream_));
+    main_stream_ = stream_;
+    KX_HIP(hipMalloc((void**)&d_dev_err_, sizeof(unsigned)));
+    KX_HIP(hipMemset(d_dev_err_, 0, sizeof(unsigned)));
     KX_HIP(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
     KX_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     KX_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
@@ -29,6 +32,9 @@ Model::~Model() {
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (stream2_) (void)hipStreamSynchronize(stream2_);
     for (void* p : owned_) (void)hipFree(p);
+    if (d_dev_err_) (void)hipFree(d_dev_err_);
+    for (auto* p : d_xchg_)
+        if (p) (void)hipFree(p);
     for (Arena* a : {&arenaT_, &arenaF_, &arenaIO_})
         if (a->base) (void)hipFree(a->base);
     if (blob_) (void)hipFree(blob_);
@@ -575,7 +581,8 @@ void Model::lstm(const LstmW& w, const T& in, const T& out, float* gx) {
     ConvOpts o;
     o.store = ST_TMAJOR;
     conv(w.ih, in, g, o);
-    launch_lstm(gx, g.bs, 2048, w.whhT, out.p, out.bs, out.ld, in.len, B_, stream_);
+    launch_lstm(gx, g.bs, 2048, w.whhT, out.p, out.bs, out.ld, in.len, B_, d_xchg_[stream_ == main_stream_ ? 0 : 1],
+                d_dev_err_, stream_);
 }
 
 // AdainResBlk1d (istftnet.py): out = (conv2(act(norm2(conv1(pool(act(norm1(x))))))) + shortcut(x)) / sqrt(2)
@@ -663,6 +670,17 @@ void Model::adain_resblock1(const std::string& name, int k, const T& x, const T&
 void Model::sync() {
     KX_HIP(hipSetDevice(device));
     KX_HIP(hipStreamSynchronize(stream_));
+    check_dev_err();
+}
+
+// (the stream is idle) raise what a kernel recorded in the sticky device error word, and clear it
+void Model::check_dev_err() {
+    unsigned e = 0;
+    KX_HIP(hipMemcpy(&e, d_dev_err_, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (!e) return;
+    KX_HIP(hipMemset(d_dev_err_, 0, sizeof(unsigned)));
+    throw Error(3, "device error word " + std::to_string(e) +
+                       ": a half of the two-CU LSTM recurrence never saw its partner (set KX_LSTM_PAIR=0 for the one-CU kernel)");
 }
 
 void Model::set_pinned(const int32_t* pattern, int n) {
@@ -794,6 +812,16 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     const int idx_ld = Tmax * 50;
     n_bs_ = 1104;
     const int noise_off = (flags & 1u) ? 1 : 0;
+    if (lstm_exchange_bytes(B) > xchg_cap_) {  // exchange buffers of the two-CU LSTM: grown like the arenas
+        KX_HIP(hipStreamSynchronize(stream_));
+        for (auto*& p : d_xchg_) {
+            if (p) KX_HIP(hipFree(p));
+            p = nullptr;
+            KX_HIP(hipMalloc((void**)&p, lstm_exchange_bytes(B)));
+            KX_HIP(hipMemset(p, 0, lstm_exchange_bytes(B)));
+        }
+        xchg_cap_ = lstm_exchange_bytes(B);
+    }
 
     // ===== front half: everything on the token axis ==========================================
     float *emb, *h, *qkv, *ctx, *av, *ff, *dcat, *gxT, *gxT2, *xl, *logits, *te0, *te1, *t_en, *d_speeds;
@@ -935,6 +963,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     // ===== the one host round trip: predicted frame counts size everything downstream =========
     KX_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));  // the TextEncoder branch joins here
     KX_HIP(hipStreamSynchronize(stream_));
+    check_dev_err();
     if (bad_id) {  // a device-side id outside the embedding tables (clamped for the gather, never read out of bounds)
         const unsigned w = bad_id - 1;
         throw Error(1, "infer: token id outside 0.." + std::to_string(n_vocab_ - 1) + " (utterance " + std::to_string(w >> 16) +
