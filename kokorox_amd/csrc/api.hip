@@ -505,6 +505,7 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
             a.n_chunks16 = (Cin + 15) / 16;
             a.w_unscale = std::ldexp(1.0f, -ws);
             a.x_prescale = 1.0f;
+            a.xcd_swizzle = 1;
             kx::launch_conv1d_f16x3(a, BM, B, transposed ? L + 1 : Lout, nullptr);
         } else {
             kx::launch_conv1d(a, BM, B, transposed ? L + 1 : Lout, nullptr);

@@ -38,7 +38,25 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, ct = blockIdx.y;
-    const int t0 = blockIdx.x * BN;
+    // XCD-aware column-tile order.  Workgroups are dealt round-robin over the 8 XCDs (linear block id mod 8), each with its
+    // own L2, and a tile's input window overlaps its neighbour's by up to 128 columns.  With tile = blockIdx.x those
+    // neighbours sit on different XCDs and the overlap is fetched from the fabric twice (PMC: 1.8x the algorithmic
+    // bytes, profiles/r02_pmc_conv_traffic_f16x3.json; the k = 3 convs run at the HBM roofline because of it).  Here
+    // the blocks of one XCD get a contiguous range of column tiles, so the overlap is an L2 hit.  (Speed only: the map
+    // is a bijection of [0, gridDim.x) for any placement.)
+    int tile_x = blockIdx.x;
+    if (a.xcd_swizzle && gridDim.x >= 16) {
+        const int nx = gridDim.x;
+        const int off = (int)(((long)nx * (blockIdx.y + (long)gridDim.y * blockIdx.z)) & 7);  // XCD class of x = 0 in this row
+        const int cls = (blockIdx.x + off) & 7;
+        int start = 0;
+        for (int c = 0; c < cls; ++c) {
+            const int first = (c - off) & 7;  // smallest x of class c
+            start += first < nx ? (nx - first + 7) >> 3 : 0;
+        }
+        tile_x = start + (blockIdx.x >> 3);   // x = first_cls + 8 j is the j-th block of its class: j = x >> 3 (first < 8)
+    }
+    const int t0 = tile_x * BN;
     const bool merged = a.merge_T > 0;
 
     const int Lin = merged ? a.merge_B * a.merge_T : a.in_len.lens[b] * a.in_len.mul + a.in_len.add;
@@ -329,7 +347,7 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
     // ---- epilogue (conv_epilogue.h); accumulators carry the 2^ws weight scale -----------------------
     if (a.dbg & 8) return;
     conv_store_tile<MT, NT, EPI_ROWS, (VT > 1)>(a, acc, a.w_unscale, b, ct * BM + wm * (MT * 32), t0 + wn * (NT * 32), r, h, ncols, Lout,
-                            blockIdx.x * WN + wn);
+                            tile_x * WN + wn);
     if (a.stamps && tid == 0) {  // stamps leave through a buffer of their own that nothing else reads
         const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         unsigned long long* o = a.stamps + (unsigned long long)lin * 8;

@@ -575,25 +575,30 @@ __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gx_bs,
 // one agent-scope (sc1) store each and polled with agent-scope loads - the data-tagged hand-off of
 // MI355X_MICROARCH.md ("R2 granule": a granule is valid when its tag is the expected step; no fence, no flag).
 // The tag carries a per-launch epoch, so the exchange buffer never needs clearing; two slots by step parity (a half
-// can only be one step ahead of its partner).  The two halves are adjacent blocks; blocks are dispatched in order, so
-// at most one pair per launch is ever waiting for a partner that is not resident yet.  Every poll is bounded: if the
+// can only be one step ahead of its partner).  The two halves are blocks i and i + 8 of a group of 16 (same XCD);
+// blocks are dispatched in order, so at most eight pairs per launch ever wait for a partner that is not resident yet.  Every poll is bounded: if the
 // partner never shows up the half raises the model's sticky error word and leaves (an error, never a hang).
 constexpr int LSTMP_REG = 24;           // float4 (4 k) pieces of a thread's 32 held in registers, the rest in LDS
 constexpr int LSTMP_LDS = 32 - LSTMP_REG;
 __global__ __launch_bounds__(1024) void lstm_pair_kernel(const float* gx, long gx_bs, int gx_ld, const float* whhT,
                                                          float* y, long y_bs, int y_ld, LenMap len,
-                                                         unsigned long long* xchg, unsigned epoch, unsigned* err) {
+                                                         unsigned long long* xchg, unsigned epoch, unsigned* err,
+                                                         int n_pairs) {
     extern __shared__ __attribute__((aligned(16))) float lstm_smem[];
     float* hs = lstm_smem;                                   // [256] h of the previous step (both halves)
-    float* part = hs + 256;                                  // [512] partial sums of the upper k half
-    float* gates = part + 512;                               // [512] gate pre-activations of this half
+    float* gates = hs + 256;                                 // [512] gate pre-activations of this half
     int* abort_flag = reinterpret_cast<int*>(gates + 512);   // [4] (one word used): a poll timed out
     float4* wl = reinterpret_cast<float4*>(gates + 512 + 4); // [LSTMP_LDS][1024] x 4 k: the tail of every thread's 128 k
-    const int hf = blockIdx.x & 1, pair = blockIdx.x >> 1;   // pair = b * 2 + dir
+    // The two halves of a pair are blocks i and i + 8 of a group of 16: blocks are dealt round-robin over the 8 XCDs, so
+    // both halves share one XCD's L2 and the hand-off does not cross the fabric (speed only: nothing depends on it).
+    const int hf = (blockIdx.x >> 3) & 1, pair = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);  // pair = b * 2 + dir
+    if (pair >= n_pairs) return;                             // (padding blocks of the last group)
     const int b = pair >> 1, dir = pair & 1, tid = threadIdx.x;
     const int L = len_of(len, b);
-    const int rr = tid & 511, kh = tid >> 9;                 // local row (gate q = rr >> 7, unit rr & 127), k half
-    const int row = (rr >> 7) * 256 + hf * 128 + (rr & 127); // row of W_hh / column of gx
+    // a wave owns 32 rows; its lower half-wave walks k 0..127 of them, the upper one k 128..255 (combined with one
+    // cross-half-wave add: no LDS round trip, no barrier)
+    const int rr = (tid >> 6) * 32 + (tid & 31), kh = (tid >> 5) & 1;  // local row (gate rr >> 7, unit rr & 127), k half
+    const int row = (rr >> 7) * 256 + hf * 128 + (rr & 127);           // row of W_hh / column of gx
     // image [k4][row][4 k] (launch_transpose_whh): k4 = kh * 32 + j covers this thread's 128 k
     const float4* W4 = reinterpret_cast<const float4*>(whhT + (long)dir * 256 * 1024) + (long)kh * 32 * 1024 + row;
     float4 wreg[LSTMP_REG];
@@ -631,10 +636,9 @@ __global__ __launch_bounds__(1024) void lstm_pair_kernel(const float* gx, long g
             acc = fmaf(w.z, hv.z, acc);
             acc = fmaf(w.w, hv.w, acc);
         }
-        if (kh) part[rr] = acc;
-        __syncthreads();
+        const float other = __shfl_xor(acc, 32);  // the other k half of the same row
         if (!kh) {
-            gates[rr] = (gxv + acc) + part[rr];
+            gates[rr] = (gxv + acc) + other;
             // the input projection of the next step (its latency hides behind the rest of this one)
             if (step + 1 < L) gxv = gxp[(long)(dir ? t - 1 : t + 1) * gx_ld];
         }
@@ -648,11 +652,11 @@ __global__ __launch_bounds__(1024) void lstm_pair_kernel(const float* gx, long g
             const float og = 1.0f / (1.0f + expf(-gates[384 + tid]));
             c = fg * c + ig * gg;
             const float hn = og * tanhf(c);
-            hs[hf * 128 + tid] = hn;
-            if (step + 1 < L) {  // publish for the partner's next step: one 8-byte agent-scope store
+            if (step + 1 < L) {  // publish for the partner's next step first: one 8-byte agent-scope store
                 const unsigned long long g8 = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(hn);
                 __hip_atomic_store(mine + par * 256 + tid, g8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            hs[hf * 128 + tid] = hn;
             y[b * y_bs + (long)(dir * 256 + hf * 128 + tid) * y_ld + t] = hn;
         } else if (tid < 256 && step + 1 < L) {
             // threads 128..255 fetch the partner's half: poll each granule until it carries this step's tag
@@ -662,13 +666,13 @@ __global__ __launch_bounds__(1024) void lstm_pair_kernel(const float* gx, long g
             for (;;) {
                 g8 = __hip_atomic_load(theirs + par * 256 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)(g8 >> 32) == tag) break;
-                if (++spins > (1 << 21)) {  // ~ seconds: the partner is not coming
+                if (++spins > (1 << 22)) {  // ~ seconds: the partner is not coming
                     atomicOr(err, 2u);
                     *abort_flag = 1;
                     g8 = 0;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                if (spins > 64) __builtin_amdgcn_s_sleep(1);  // (a tight poll while the partner is a fraction of a step away)
             }
             hs[(1 - hf) * 128 + j] = __uint_as_float((unsigned)(g8 & 0xffffffffu));
         }
@@ -688,7 +692,7 @@ void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, floa
                  LenMap len, int B, unsigned long long* xchg, unsigned* err_word, hipStream_t s) {
     static_assert(LSTM_LDS_K % 4 == 0 && LSTM_REG_K % 4 == 0, "whole float4 groups of h");
     if (lstm_use_pair() && xchg && err_word) {
-        const size_t lds = sizeof(float) * (256 + 512 + 512 + 4 + (size_t)LSTMP_LDS * 1024 * 4);
+        const size_t lds = sizeof(float) * (256 + 512 + 4 + (size_t)LSTMP_LDS * 1024 * 4);
         static bool pair_attr = false;
         if (!pair_attr) {
             KX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_pair_kernel),
@@ -698,8 +702,9 @@ void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, floa
         static std::atomic<unsigned> epoch_ctr{0};
         unsigned epoch = (epoch_ctr.fetch_add(1) + 1) & 0xffffu;
         if (epoch == 0) epoch = (epoch_ctr.fetch_add(1) + 1) & 0xffffu;  // (0 is what a fresh buffer holds)
-        hipLaunchKernelGGL(lstm_pair_kernel, dim3(B * 2 * 2), dim3(1024), lds, s, gx, gx_bs, gx_ld, whhT, y, y_bs, y_ld, len,
-                           xchg, epoch, err_word);
+        const int n_pairs = B * 2;  // (utterance, direction); blocks come in groups of 16 = 8 pairs
+        hipLaunchKernelGGL(lstm_pair_kernel, dim3(((n_pairs + 7) / 8) * 16), dim3(1024), lds, s, gx, gx_bs, gx_ld, whhT, y, y_bs,
+                           y_ld, len, xchg, epoch, err_word, n_pairs);
         KX_HIP(hipGetLastError());
         return;
     }

@@ -90,6 +90,7 @@ struct ConvArgs {
     int merge_B;
     float2* stat_part;  // optional [B][Cout][stat_tiles] partial (sum, sum of squares) of the stored values
     int stat_tiles;
+    int xcd_swizzle;               // one-role f16x3 kernel: contiguous column tiles per XCD (1 unless KX_XCD_SWIZZLE=0)
     int ws_force;                  // test hook: 1 = take the wave-specialised kernel when the shape is eligible
     int ws_ntx, ws_nty, ws_tiles;  // persistent wave-specialised kernel: column tiles, row tiles, all tiles (set by its launcher)
     unsigned long long* stamps;  // diagnostic build only: per-workgroup {t0,t1,t2,t3,hw_id,xcc_id,0,0}

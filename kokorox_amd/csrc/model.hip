@@ -428,6 +428,8 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     const bool f16 = conv_mode == CONV_F16X3;
     a.w16 = w.w16;
     a.n_chunks16 = w.n_chunks16;
+    static const int xcd_swz = getenv("KX_XCD_SWIZZLE") ? atoi(getenv("KX_XCD_SWIZZLE")) : 1;
+    a.xcd_swizzle = xcd_swz;
     a.x_prescale = std::ldexp(1.0f, w.act_shift);
     a.w_unscale = std::ldexp(w.unscale, -w.act_shift);  // (exact: both are powers of two)
     if (diag_on_ && diag_used_ < diag_cap_) {
