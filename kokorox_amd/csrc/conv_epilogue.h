@@ -5,6 +5,21 @@
 #pragma once
 #include "kx_common.h"
 
+// epilogue load batches (EB rows x NT tiles) in flight ahead of the stores; "SMALL" = waves with fewer than 8 accumulator
+// tiles, which run at three workgroups per CU under a 168-register cap
+#ifndef KX_EPI_DEPTH_R
+#define KX_EPI_DEPTH_R 5  // residual form
+#endif
+#ifndef KX_EPI_DEPTH_A
+#define KX_EPI_DEPTH_A 2  // residual + running-sum form (two loads per element)
+#endif
+#ifndef KX_EPI_DEPTH_R_SMALL
+#define KX_EPI_DEPTH_R_SMALL 3
+#endif
+#ifndef KX_EPI_DEPTH_A_SMALL
+#define KX_EPI_DEPTH_A_SMALL 1
+#endif
+
 namespace kx {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -46,11 +61,18 @@ using buf_rsrc = __amdgpu_buffer_rsrc_t;
 __device__ __forceinline__ buf_rsrc make_buf(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);  // raw, 4 GiB window
 }
+// cache policy of the epilogue's accesses (aux operand: 1 = sc0, 2 = nt, 4 = sc1)
+#ifndef KX_EPI_LD_AUX
+#define KX_EPI_LD_AUX 0
+#endif
+#ifndef KX_EPI_ST_AUX
+#define KX_EPI_ST_AUX 0
+#endif
 __device__ __forceinline__ float buf_load(buf_rsrc rs, unsigned lane_bytes, unsigned uniform_bytes) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane_bytes, uniform_bytes, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane_bytes, uniform_bytes, KX_EPI_LD_AUX));
 }
 __device__ __forceinline__ void buf_store(buf_rsrc rs, unsigned lane_bytes, unsigned uniform_bytes, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, lane_bytes, uniform_bytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, lane_bytes, uniform_bytes, KX_EPI_ST_AUX);
 }
 
 // Store of one wave's MT x NT block of 32x32 accumulator tiles, channel-major or time-major, with bias, residual,
@@ -66,7 +88,8 @@ __device__ __forceinline__ void buf_store(buf_rsrc rs, unsigned lane_bytes, unsi
 //           (edge blocks only; the compile-time forms keep the common path free of per-row branches)
 template <int MT, int NT, int EB, int LOADS, bool FULL, bool GELU>
 __device__ __forceinline__ void conv_store_rmw(const ConvArgs& a, f32x16 (&acc)[MT][NT], float acc_scale, int b,
-                                               int row0, int col0, int r, int h, int ncols, int stat_slot) {
+                                               int row0, int col0, int r, int h, int ncols, int stat_slot,
+                                               float2* stat_scr) {
     const bool tmaj = a.store == ST_TMAJOR;
     const bool has_bias = a.bias != nullptr;
     const bool has_res = LOADS == 3 ? (a.resid != nullptr && !tmaj) : (LOADS >= 1);
@@ -74,8 +97,10 @@ __device__ __forceinline__ void conv_store_rmw(const ConvArgs& a, f32x16 (&acc)[
     constexpr bool ACCUM = LOADS >= 2;  // (whether the y read-back buffers exist)
     const int cmax = ncols - 1, rmax = a.Cout - 1;
     const bool merged = a.merge_T > 0;
-    const unsigned yrs = 4u * (tmaj ? 1u : (unsigned)a.y_ld);  // row strides in bytes
-    const unsigned rrs = 4u * (unsigned)a.r_ld;
+    // row strides in bytes (timing ablations, results wrong: KX_DBG bit 32 stores every row of the tensor over row 0,
+    // bit 64 reads the residual / running sum from row 0 -- same instruction stream, no HBM traffic behind it)
+    const unsigned yrs = (a.dbg & 32) ? 0u : 4u * (tmaj ? 1u : (unsigned)a.y_ld);
+    const unsigned rrs = (a.dbg & 64) ? 0u : 4u * (unsigned)a.r_ld;
     const buf_rsrc ybuf = make_buf(a.y + (merged ? 0 : (long)b * a.y_bs));
     const buf_rsrc rbuf = make_buf(has_res ? a.resid + (merged ? 0 : (long)b * a.r_bs) : a.y);
     // bias of the wave's MT * 32 <= 64 rows: one value per lane, handed out below with v_readlane
@@ -128,7 +153,13 @@ __device__ __forceinline__ void conv_store_rmw(const ConvArgs& a, f32x16 (&acc)[
     const float div_d = a.out_div, div_rd = 1.0f / a.out_div;
     const bool gelu = GELU && a.epi == EPI_GELU_NEW;
     const bool want_stats = a.stat_part != nullptr;
-    constexpr int DEPTH = ACCUM ? 1 : 2;  // load batches in flight ahead of the one being stored
+    // load batches in flight ahead of the one being stored.  The epilogue of a tile is a chain of memory round trips
+    // (a batch is stored only after its residual / running-sum values are back, ~2 us under this kernel's own load), so
+    // its length is (batches / DEPTH) x latency; the staging registers of the main loop are dead here, which pays for
+    // the deeper queues of the compile-time forms.
+    constexpr bool BIG = MT * NT >= 8;
+    constexpr int DEPTH = LOADS == 1 ? (BIG ? KX_EPI_DEPTH_R : KX_EPI_DEPTH_R_SMALL)
+                        : LOADS == 2 ? (BIG ? KX_EPI_DEPTH_A : KX_EPI_DEPTH_A_SMALL) : (ACCUM ? 1 : 2);
     constexpr int NBUF = DEPTH + 1;
     float rv[NBUF][EB][NT], yv[NBUF][ACCUM ? EB : 1][NT];
     auto load_batch = [&](int bi, float (&rvb)[EB][NT], float (&yvb)[ACCUM ? EB : 1][NT]) {
@@ -189,9 +220,28 @@ __device__ __forceinline__ void conv_store_rmw(const ConvArgs& a, f32x16 (&acc)[
                 rs += vm;
                 rq += vm * vm;
             }
-            if (want_stats) {
-                // fused InstanceNorm statistics of what was just stored: reduce the row's partial over the 32 lanes
-                // of this half-wave (lanes = columns), one (sum, sumsq) per row and column slot
+            if (want_stats && stat_scr != nullptr) {
+                // fused InstanceNorm statistics of what was just stored, LDS form: every lane parks the partial of its row
+                // (its column of the NT tiles) in the wave's scratch [32 tile rows][32 columns + 1]; when the tile's 32
+                // rows are complete, lane l < 32 adds up row l.  One ds_write_b64 per register row and 32 ds_read_b64 +
+                // 64 adds per tile, against a 5-step DPP reduction of two values per register row (measured: the
+                // reductions were ~2/3 of the epilogue's instructions, and the epilogue 11-14 % of the kernel).
+                // LDS operations of one wave execute in order, so no barrier is involved.
+                stat_scr[((e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r] = make_float2(rs, rq);
+                if (eg == NEG - 1 && e8 == EB - 1 && h == 0) {
+                    float2 t = stat_scr[r * 33];
+#pragma unroll
+                    for (int j = 1; j < 32; ++j) {
+                        const float2 pj = stat_scr[r * 33 + j];
+                        t.x += pj.x;
+                        t.y += pj.y;
+                    }
+                    const int rowg = row0 + mt * 32 + r;
+                    if (FULL || rowg <= rmax) a.stat_part[((long)b * a.Cout + rowg) * a.stat_tiles + stat_slot] = t;
+                }
+            } else if (want_stats) {
+                // DPP form (kernels without LDS to spare): reduce the row's partial over the 32 lanes of this half-wave
+                // (lanes = columns), one (sum, sumsq) per row and column slot
                 const float sv = half_wave_sum(rs), qv = half_wave_sum(rq);
                 if (r == HALF_WAVE_SUM_LANE && rok)
                     a.stat_part[((long)b * a.Cout + rowu + 4 * h) * a.stat_tiles + stat_slot] = make_float2(sv, qv);
@@ -204,21 +254,22 @@ __device__ __forceinline__ void conv_store_rmw(const ConvArgs& a, f32x16 (&acc)[
 // EB = rows per load batch of the read-modify-write path
 template <int MT, int NT, int EB, bool GELU>
 __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)[MT][NT], float acc_scale, int b,
-                                                int row0, int col0, int r, int h, int ncols, int Lout, int stat_slot) {
+                                                int row0, int col0, int r, int h, int ncols, int Lout, int stat_slot,
+                                                float2* stat_scr = nullptr) {
     if (a.store == ST_NORMAL || a.store == ST_TMAJOR) {
         const bool full = row0 + MT * 32 <= a.Cout && col0 + NT * 32 <= ncols;  // wave-uniform
         const bool res = a.resid != nullptr && a.store == ST_NORMAL;
         const bool accum = a.accum != 0 && a.store == ST_NORMAL;
         if (!full)
-            conv_store_rmw<MT, NT, EB, 3, false, GELU>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot);
+            conv_store_rmw<MT, NT, EB, 3, false, GELU>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot, stat_scr);
         else if (res && accum)
-            conv_store_rmw<MT, NT, EB, 2, true, GELU>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot);
+            conv_store_rmw<MT, NT, EB, 2, true, GELU>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot, stat_scr);
         else if (res)
-            conv_store_rmw<MT, NT, EB, 1, true, GELU>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot);
+            conv_store_rmw<MT, NT, EB, 1, true, GELU>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot, stat_scr);
         else if (!accum)
-            conv_store_rmw<MT, NT, EB, 0, true, GELU>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot);
+            conv_store_rmw<MT, NT, EB, 0, true, GELU>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot, stat_scr);
         else  // accumulate without a residual: not a form the graph has; the edge path handles any combination
-            conv_store_rmw<MT, NT, EB, 3, false, GELU>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot);
+            conv_store_rmw<MT, NT, EB, 3, false, GELU>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot, stat_scr);
         return;
     }
     // ST_UPSCATTER: polyphase transposed conv, GEMM row (p, co), column q -> out[co][s*q + p - pad]

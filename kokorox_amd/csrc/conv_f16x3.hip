@@ -346,8 +346,11 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
     if (a.stamps) st2 = __builtin_amdgcn_s_memrealtime();
     // ---- epilogue (conv_epilogue.h); accumulators carry the 2^ws weight scale -----------------------
     if (a.dbg & 8) return;
+    // (all of the LDS is free after the main loop's last barrier: each wave takes 8.25 KiB of it as the scratch of the
+    // statistics reduction; the smallest allocation, BM = 32 without the fixed window pitch, is too small for four of them)
+    float2* stat_scr = (BM >= 64 || PF) ? reinterpret_cast<float2*>(smem16) + wave * (32 * 33) : nullptr;
     conv_store_tile<MT, NT, EPI_ROWS, (VT > 1)>(a, acc, a.w_unscale, b, ct * BM + wm * (MT * 32), t0 + wn * (NT * 32), r, h, ncols, Lout,
-                            tile_x * WN + wn);
+                            tile_x * WN + wn, stat_scr);
     if (a.stamps && tid == 0) {  // stamps leave through a buffer of their own that nothing else reads
         const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         unsigned long long* o = a.stamps + (unsigned long long)lin * 8;
@@ -415,7 +418,10 @@ static void launch_inst16_tk(const ConvArgs& a, int B, int max_cols, hipStream_t
 template <int BM, int BN, int WM, int WN>
 static void launch_inst16(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
     // (weight pieces of 1 and 2 taps were measured too: no faster than 3 anywhere, so only TK = 3 is built)
-    launch_inst16_tk<BM, BN, WM, WN, 3>(a, B, max_cols, s);
+#ifndef KX_TK
+#define KX_TK 3
+#endif
+    launch_inst16_tk<BM, BN, WM, WN, KX_TK>(a, B, max_cols, s);
 }
 
 // Tile of a launch: BN columns per workgroup, WN = waves side by side along the columns.

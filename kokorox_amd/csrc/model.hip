@@ -470,7 +470,10 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     long n_wg = 0;
     static const int stamp_rows = getenv("KX_STAMP_ROWS") ? atoi(getenv("KX_STAMP_ROWS")) : 128;
     static const int stamp_k = getenv("KX_STAMP_K") ? atoi(getenv("KX_STAMP_K")) : 11;
-    if (stamp_path && !stamped && f16 && w.K == stamp_k && w.rows == stamp_rows && B_ >= 8) {
+    static int stamp_skip = getenv("KX_STAMP_SKIP") ? atoi(getenv("KX_STAMP_SKIP")) : 0;  // matching launches to pass over first
+    const bool stamp_match = stamp_path && !stamped && f16 && w.K == stamp_k && w.rows == stamp_rows && B_ >= 8 && !dry_;
+    if (stamp_match && stamp_skip > 0) --stamp_skip;
+    else if (stamp_match) {
         n_wg = (long)((max_cols + 127) / 128) * ((w.rows + 127) / 128) * (a.merge_T > 0 ? 1 : B_);
         KX_HIP(hipMalloc((void**)&d_stamps, n_wg * 64));
         KX_HIP(hipMemsetAsync(d_stamps, 0, n_wg * 64, stream_));
