@@ -401,9 +401,9 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
         KX_HIP(hipSetDevice(device_id));
         DevMem dm;
         std::vector<int> lens(B, 1);
-        KX_REQUIRE(mode >= kx::CONV_F32 && mode <= kx::CONV_F16X3_WS, "test_conv1d: mode must be 0, 1 or 2");
+        KX_REQUIRE(mode >= kx::CONV_F32 && mode <= kx::CONV_F16X3_DA, "test_conv1d: mode must be 0, 1, 2 or 3");
         kx::ConvArgs a{};
-        a.ws_force = mode == kx::CONV_F16X3_WS ? 1 : 0;
+        a.ws_force = mode == kx::CONV_F16X3_WS ? 1 : (mode == kx::CONV_F16X3_DA ? 2 : 0);
         a.x = dm.up(x, (size_t)B * Cin * L);
         a.x_bs = (long)Cin * L;
         a.x_ld = L;

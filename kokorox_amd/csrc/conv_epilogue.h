@@ -8,13 +8,13 @@
 // epilogue load batches (EB rows x NT tiles) in flight ahead of the stores; "SMALL" = waves with fewer than 8 accumulator
 // tiles, which run at three workgroups per CU under a 168-register cap
 #ifndef KX_EPI_DEPTH_R
-#define KX_EPI_DEPTH_R 5  // residual form
+#define KX_EPI_DEPTH_R 2  // residual form (deeper queues were measured: 5 = no gain, 7 = slower)
 #endif
 #ifndef KX_EPI_DEPTH_A
-#define KX_EPI_DEPTH_A 2  // residual + running-sum form (two loads per element)
+#define KX_EPI_DEPTH_A 1  // residual + running-sum form (two loads per element)
 #endif
 #ifndef KX_EPI_DEPTH_R_SMALL
-#define KX_EPI_DEPTH_R_SMALL 3
+#define KX_EPI_DEPTH_R_SMALL 2
 #endif
 #ifndef KX_EPI_DEPTH_A_SMALL
 #define KX_EPI_DEPTH_A_SMALL 1
@@ -204,7 +204,10 @@ __device__ __forceinline__ void conv_store_rmw(const ConvArgs& a, f32x16 (&acc)[
             float rs = 0.f, rq = 0.f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                float v = acc[mt][nt][e] * acc_scale + bvv;
+                // (every multiply-add of the epilogue is an explicit fma: left to -ffp-contract, the same source fused or
+                // not depending on how the surrounding kernel was vectorised, and batch members then differed from their
+                // batch-of-one runs in the last bit of the statistics)
+                float v = __builtin_fmaf(acc[mt][nt][e], acc_scale, bvv);
                 if (LOADS == 3) {
                     if (has_loads) v += rv[bi % NBUF][e8][nt] + yv[bi % NBUF][e8][nt];
                 } else {
@@ -218,7 +221,7 @@ __device__ __forceinline__ void conv_store_rmw(const ConvArgs& a, f32x16 (&acc)[
                 if (FULL || (rok && cok[nt])) stv(ybuf, yoff[nt], yt, v);
                 const float vm = (FULL || cok[nt]) ? v : 0.f;
                 rs += vm;
-                rq += vm * vm;
+                rq = __builtin_fmaf(vm, vm, rq);
             }
             if (want_stats && stat_scr != nullptr) {
                 // fused InstanceNorm statistics of what was just stored, LDS form: every lane parks the partial of its row
@@ -326,7 +329,7 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)
                     const float bvv = h ? b1 : b0;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        buf_store(ybuf, qoff[nt] + yts[e4], 0u, acc[mt][nt][e] * acc_scale + bvv + rv[e4][nt]);
+                        buf_store(ybuf, qoff[nt] + yts[e4], 0u, __builtin_fmaf(acc[mt][nt][e], acc_scale, bvv) + rv[e4][nt]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -350,7 +353,7 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)
                 if (col >= ncols) continue;
                 const int tout = a.up_s * col + p - a.up_pad;
                 if (tout < 0 || tout >= Lout) continue;
-                const float v = acc[mt][nt][e] * acc_scale + bv;
+                const float v = __builtin_fmaf(acc[mt][nt][e], acc_scale, bv);
                 const long off = (long)co * a.y_ld + tout + a.up_off;
                 float o = v;
                 if (rb) o += rb[(long)co * a.r_ld + tout + a.up_off];

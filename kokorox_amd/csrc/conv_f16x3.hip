@@ -106,6 +106,10 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
         uint4* dst = Wbuf + buf * piece_units;
         const int nseg = taps * tap_units / 64;
         if (a.dbg & 2) return;
+        if (a.dbg & 256) {  // timing ablation: the same copy instructions, every one reading the first KiB of the image
+            for (int sgm = wave; sgm < nseg; sgm += NWV) glds16(wbase + lane, dst + sgm * 64);
+            return;
+        }
         for (int sgm = wave; sgm < nseg; sgm += NWV) glds16(src + sgm * 64 + lane, dst + sgm * 64);
     };
 
@@ -151,8 +155,8 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
         pv[0] = has_norm ? a.nmean[(long)b * a.n_bs + cc] : 0.f;
         pv[1] = has_norm ? a.nscale[(long)b * a.n_bs + cc] : 1.f;
         pv[2] = has_norm ? a.nshift[(long)b * a.n_bs + cc] : 0.f;
-        const float al = (ACT == ACT_SNAKE) ? a.alpha[cc] : 1.f;
-        pv[3] = (lane & 8) ? 1.0f / al : al;  // lanes 8..15: the reciprocals
+        pv[3] = (ACT == ACT_SNAKE) ? a.alpha[cc] : 1.f;  // (its reciprocal is taken when the chunk is transformed: a
+                                                          // division here would wait for the load on the spot)
     };
     auto load_raw = [&](int sc) {
 #pragma unroll
@@ -171,13 +175,14 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
     // per-channel parameters of one octet, unpacked into scalar registers once per chunk
     struct Oct { float m[8], s[8], h[8], al[8], ial[8]; };
     auto unpack_params = [&](const float (&pv)[4], Oct& o) {
+        const float al_or_rcp = (lane & 8) ? 1.0f / pv[3] : pv[3];  // lanes 8..15: the reciprocals
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             o.m[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv[0]), c));
             o.s[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv[1]), c));
             o.h[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv[2]), c));
-            o.al[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv[3]), c));
-            o.ial[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv[3]), c + 8));
+            o.al[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al_or_rcp), c));
+            o.ial[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al_or_rcp), c + 8));
         }
     };
     // transform one column's 8 channels and write its two 16-byte slots
@@ -190,7 +195,7 @@ void conv1d_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int c = 2 * c2 + q;
-                const float y = in_act<ACT>((x8[c] - o.m[c]) * o.s[c] + o.h[c], a.slope, o.al[c], o.ial[c]);
+                const float y = in_act<ACT>(__builtin_fmaf(x8[c] - o.m[c], o.s[c], o.h[c]), a.slope, o.al[c], o.ial[c]);  // (explicit fma: see conv_epilogue.h)
                 // zero padding comes after the activation (a multiply, so that the activation stays branch-free;
                 // masked positions hold clamped-address tensor values, i.e. finite numbers)
                 y2[q] = y * ((ch * CK16 + g * 8 + c <= cmax_in) ? keep : 0.f);
@@ -431,8 +436,12 @@ static void launch_inst16(const ConvArgs& a, int B, int max_cols, hipStream_t s)
 //   the 256-wide tile and results stay bit-identical across batch sizes.
 void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int stride, int* bn, int* wn, int ws_force) {
     static const int force = env_int("KX_BN", 0);
-    if (conv16_use_ws(BM, K, dil, stride, 0) || (ws_force && conv16_ws_eligible(BM, K, dil, stride, 0))) {
+    if (conv16_use_ws(BM, K, dil, stride, 0) || (ws_force == 1 && conv16_ws_eligible(BM, K, dil, stride, 0))) {
         conv16_ws_tile(max_cols, B, Cout, bn, wn);
+        return;
+    }
+    if (ws_force == 2 && conv16_da_eligible(BM, K, dil, stride, 0)) {  // test hook: the direct-A kernel whatever the grid
+        *bn = 256; *wn = 2;
         return;
     }
     if (BM != 128) {
@@ -447,11 +456,15 @@ void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int
 }
 
 void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStream_t s) {
+#ifdef KX_ONLY_MAIN  // (compile-time probe builds: just the dominant instantiation, ~10 s instead of ~3 min)
+    launch_inst16_pf<128, 256, 2, 2, ACT_SNAKE, 3, true>(a, B, max_cols, s);
+    return;
+#else
     KX_REQUIRE(a.n_chunks16 == (a.Cin + CK16 - 1) / CK16 && a.w16 != nullptr, "conv1d f16x3: weights not packed");
     KX_REQUIRE(BM == 128 || a.epi != EPI_GELU_NEW, "conv1d f16x3: gelu epilogue needs the 128-row tile");
     if (max_cols <= 0) return;
     if (conv16_use_ws(BM, a.K, a.dil, a.stride, a.merge_T > 0) ||
-        (a.ws_force && conv16_ws_eligible(BM, a.K, a.dil, a.stride, a.merge_T > 0))) {
+        (a.ws_force == 1 && conv16_ws_eligible(BM, a.K, a.dil, a.stride, a.merge_T > 0))) {
         launch_conv1d_f16x3_ws(a, B, max_cols, s);
         return;
     }
@@ -474,6 +487,8 @@ void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStre
             launch_inst16<128, 128, 4, 1>(a, B, max_cols, s);
         else if (bn == 128)
             launch_inst16<128, 128, 2, 2>(a, B, max_cols, s);
+        else if (conv16_use_da(BM, a.K, a.dil, a.stride, a.merge_T > 0))
+            launch_conv1d_f16x3_da(a, B, max_cols, s);
         else
             launch_inst16<128, 256, 2, 2>(a, B, max_cols, s);
     } else if (BM == 64)
@@ -482,6 +497,7 @@ void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStre
         launch_inst16<32, 256, 1, 4>(a, B, max_cols, s);
     else
         throw Error(1, "conv1d f16x3: unsupported BM");
+#endif
 }
 
 // ---- weight repacking into split-f16 fragment images -------------------------------------------------

@@ -195,7 +195,7 @@ void conv1d_f16x3_ws_kernel(const ConvArgs a) {
                     float y[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const float v = in_act<ACT>((raw[j][c] - m[c]) * sc[c] + hh[c], a.slope, al[c], ial[c]);
+                        const float v = in_act<ACT>(__builtin_fmaf(raw[j][c] - m[c], sc[c], hh[c]), a.slope, al[c], ial[c]);
                         // zero padding comes after the activation (a multiply keeps the activation branch-free;
                         // masked positions hold clamped-address tensor values, i.e. finite numbers)
                         y[c] = v * (keep[j] * cv[c]);

@@ -91,7 +91,7 @@ struct ConvArgs {
     float2* stat_part;  // optional [B][Cout][stat_tiles] partial (sum, sum of squares) of the stored values
     int stat_tiles;
     int xcd_swizzle;               // one-role f16x3 kernel: contiguous column tiles per XCD (1 unless KX_XCD_SWIZZLE=0)
-    int ws_force;                  // test hook: 1 = take the wave-specialised kernel when the shape is eligible
+    int ws_force;                  // test hook: 1 = take the wave-specialised kernel when the shape is eligible, 2 = the direct-A kernel
     int ws_ntx, ws_nty, ws_tiles;  // persistent wave-specialised kernel: column tiles, row tiles, all tiles (set by its launcher)
     unsigned long long* stamps;  // diagnostic build only: per-workgroup {t0,t1,t2,t3,hw_id,xcc_id,0,0}
     int dbg;  // timing ablations (env KX_DBG): 1 skip input staging, 2 skip weight copies, 4 skip MFMA, 8 skip epilogue
@@ -116,7 +116,7 @@ void launch_pack_convT(const float* w, float* dst, int Cin, int Cout, int s, int
 size_t packed_conv_floats(int rows, int Cin, int K, int BM);
 
 // f16x3 split path
-enum ConvMode { CONV_F32 = 0, CONV_F16X3 = 1, CONV_F16X3_WS = 2 };  // (2: test hook only, f16x3 through conv_f16x3_ws.hip)
+enum ConvMode { CONV_F32 = 0, CONV_F16X3 = 1, CONV_F16X3_WS = 2, CONV_F16X3_DA = 3 };  // (2, 3: test hook only: f16x3 forced through conv_f16x3_ws.hip / conv_f16x3_da.hip)
 void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStream_t s);
 void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int stride, int* bn, int* wn,
                       int ws_force = 0);  // (conv_f16x3.hip)
@@ -125,6 +125,10 @@ bool conv16_use_ws(int BM, int K, int dil, int stride, int merged);       // eli
 bool conv16_ws_eligible(int BM, int K, int dil, int stride, int merged);  // shape fits the kernel
 void conv16_ws_tile(int max_cols, int B, int Cout, int* bn, int* wn);
 void launch_conv1d_f16x3_ws(const ConvArgs& a, int B, int max_cols, hipStream_t s);
+// conv_f16x3_da.hip: the 128 x 256 tile with the weight fragments loaded from global memory straight into registers
+bool conv16_use_da(int BM, int K, int dil, int stride, int merged);       // eligible AND switched on (default; KX_DA=0 turns it off)
+bool conv16_da_eligible(int BM, int K, int dil, int stride, int merged);  // shape fits the kernel
+void launch_conv1d_f16x3_da(const ConvArgs& a, int B, int max_cols, hipStream_t s);
 size_t packed_conv16_halves(int rows, int Cin, int K, int BM);
 float device_absmax(const float* p, long n, hipStream_t s);
 int pick_weight_shift(float absmax);

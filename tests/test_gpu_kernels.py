@@ -27,7 +27,7 @@ CONV_CASES = [
 ]
 
 
-MODES = [pytest.param(0, id="f32"), pytest.param(1, id="f16x3"), pytest.param(2, id="f16x3ws")]
+MODES = [pytest.param(0, id="f32"), pytest.param(1, id="f16x3"), pytest.param(2, id="f16x3ws"), pytest.param(3, id="f16x3da")]
 
 
 @pytest.mark.parametrize("mode", MODES)

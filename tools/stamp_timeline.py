@@ -54,3 +54,9 @@ print("timeline (bin start us: resident / staging / epilogue):")
 step = max(1, nb // 40)
 for i in range(0, nb, step):
     print(f"  {i * binw:7.0f}: {res[i]:5.0f} {stg[i]:6.1f} {epi[i]:6.1f}")
+if len(sys.argv) > 3 and sys.argv[3] == "drain":  # KX_DBG=128: o[6] = stamp taken before the final s_waitcnt of wave 0
+    pre = (d[:, 6] - t0).astype(np.float64) / 100.0
+    x = st[3] - pre
+    y = pre - st[2]
+    print(f"epilogue issue part p50 {np.median(y):.1f} us (p10 {np.percentile(y,10):.1f}, p90 {np.percentile(y,90):.1f}); "
+          f"drain of the stores after the last one was issued p50 {np.median(x):.1f} us (p10 {np.percentile(x,10):.1f}, p90 {np.percentile(x,90):.1f})")
