@@ -22,8 +22,20 @@
 // order, so results are bit-identical to the other tile shapes (batch invariance, tests/test_gpu_forward.py).
 // Eligible launches: 128-row weight tiles, stride 1, window <= 384 columns, not the merged token-axis form.
 #include "conv_f16x3_common.h"
+#include <type_traits>
+
 
 namespace kx {
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N - 1 (indices that must be constants BEFORE any loop
+// is unrolled: register arrays indexed through an unrolled loop variable stayed in scratch in the largest instantiation)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 bool conv16_da_eligible(int BM, int K, int dil, int stride, int merged) {
     return BM == 128 && stride == 1 && !merged && (K - 1) * dil + 256 <= 384;
@@ -33,7 +45,7 @@ bool conv16_use_da(int BM, int K, int dil, int stride, int merged) {
     return on && conv16_da_eligible(BM, K, dil, stride, merged);
 }
 
-template <int ACT>
+template <int ACT, int KT>
 __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs a) {
     constexpr int BM = 128, BN = 256, NT = 8;
     constexpr int XWp = BN + 128;           // window pitch of one image row (columns)
@@ -66,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
     const int ncols = (a.store == ST_UPSCATTER) ? (Lin + 1) : Lout;
     if (t0 >= ncols) return;
 
-    const int K = a.K, dil = a.dil;
+    const int K = KT > 0 ? KT : a.K, dil = a.dil;
     const int n_chunks = a.n_chunks16;
     const int n_steps = n_chunks * K;
     const float* xb = a.x + (long)b * a.x_bs;
@@ -153,6 +165,69 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
         for (int j = 0; j < NJ; ++j) emit8(Xb, ch, lane + 64 * (jb + 2 * j), raw[j], o, ((okmask >> j) & 1u) != 0u);
     };
 
+    // ---- the same transform cut into 12 units of one column block x one channel pair (2 of the lane's 24 elements),
+    // each in two halves of one element (~25 vector instructions; the second half packs the pair and writes its two
+    // dwords of the image), to be issued BETWEEN the MFMAs of 24 consecutive column tiles = three steps.
+    // Measured (profiles/r02_da_ablations.txt): the transform of a chunk, done in one piece at the chunk's end, costs
+    // exactly its own duration (7.2 of 24.8 ms on the k = 11 launches; dropping it, loads kept: 17.7 ms): the partner
+    // workgroup's MFMAs do not fill the gap (two co-resident workgroups that start together stay in phase).  A wave's own
+    // MFMAs do: the matrix pipe runs an MFMA for 32 cycles while the wave's vector instructions keep issuing.
+    float al_rcp_x = 1.f;  // (alpha | 1 / alpha by lane, set by the first part of a chunk's transform)
+    float y_carry = 0.f;   // (first element of a pair, from half 0 to half 1)
+    float xt_ = 0.f, xz_ = 0.f;  // (state of the element in flight: the affine value, then z = r^2 / sin^2)
+    // One element of the transform in three parts, placed behind the three MFMAs of a column tile.  The arithmetic is that
+    // of emit8 / in_act / sin_sq, operation for operation (results must not depend on where a chunk was transformed).
+    // U: unit (column block U / 4, channel pair U % 4), half: element of the pair; both constants once inlined.
+    auto xform_a = [&](const int U, const int half, int ch) __attribute__((always_inline)) {
+        const int j = U / 4, cq = 2 * (U % 4) + half;
+        if (U == 0 && half == 0) al_rcp_x = (lane & 8) ? 1.0f / praw[3] : praw[3];
+        const float m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, praw[0]), cq));
+        const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, praw[1]), cq));
+        const float sh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, praw[2]), cq));
+        xt_ = __builtin_fmaf(raw[j][cq] - m, sc, sh);
+        if (ACT == ACT_SNAKE) {
+            const float al = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al_rcp_x), cq));
+            const float t = al * xt_;
+            const float n = rintf(t * 0.318309886183790672f);
+            float rr = fmaf(n, -3.14159274101257324f, t);
+            rr = fmaf(n, 8.74227765734758578e-08f, rr);
+            xz_ = rr * rr;
+        }
+    };
+    auto xform_b = [&]() __attribute__((always_inline)) {
+        if (ACT == ACT_SNAKE) {
+            const float z = xz_;
+            float pp = fmaf(z, -3.6197402550897095e-06f, 1.3928599946666651e-04f);
+            pp = fmaf(z, pp, -3.1722760759294033e-03f);
+            pp = fmaf(z, pp, 4.4443082064390182e-02f);
+            pp = fmaf(z, pp, -3.3333304524421692e-01f);
+            pp = fmaf(z, pp, 1.0f);
+            xz_ = z * pp;
+        }
+    };
+    auto xform_c = [&](const int U, const int half, uint4* Xb, int ch) __attribute__((always_inline)) {
+        const int j = U / 4, c2 = U % 4, cq = 2 * c2 + half;
+        float y;
+        if (ACT == ACT_SNAKE) {
+            const float ial = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al_rcp_x), cq + 8));
+            y = fmaf(ial, xz_, xt_);
+        } else {
+            y = in_act<ACT>(xt_, a.slope, 1.f, 1.f);
+        }
+        const float keep = ((okmask >> j) & 1u) ? a.x_prescale : 0.f;
+        y = y * ((ch * CK16 + g * 8 + cq <= cmax_in) ? keep : 0.f);
+        if (half == 0) {
+            y_carry = y;
+        } else {
+            unsigned hp, lp;
+            split_pair(y_carry, y, hp, lp);
+            const int u = lane + 64 * (jb + 2 * j);
+            unsigned* Xw = reinterpret_cast<unsigned*>(Xb);
+            Xw[((0 * 2 + g) * XWp + u) * 4 + c2] = hp;
+            Xw[((1 * 2 + g) * XWp + u) * 4 + c2] = lp;
+        }
+    };
+
     // ---- A fragments: lane (row r, k-half h) of wave w reads 16 B at [step][hi|lo][h][32 w + r].
     // The loads are inline asm with hand-counted waits.  Left to the compiler, the ring (a loop-carried set of pending
     // loads whose age differs between the paths into the loop header) gets an s_waitcnt vmcnt(0) at every loop header:
@@ -193,50 +268,157 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
     load_A(1, ah1, al1);
     load_A(2, ah2, al2);
 
+    // (experiment, KX_DBG bit 16384: the second workgroup that ever lands on a CU in this launch starts its main loop late by
+    // a.ws_tiles x 64 cycles, so that the two co-resident workgroups are out of phase; a.stamps doubles as the per-CU counters)
+    int late = 0;
+    if ((a.dbg & 16384) && a.stamps) {
+        const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+        const unsigned cu = ((xcc & 7u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+        unsigned long long old = 0;
+        if (tid == 0) old = atomicAdd(a.stamps + cu, 1ull);
+        late = __builtin_amdgcn_readfirstlane((int)old) == 1 ? 1 : 0;
+    }
     load_raw(0);
     stage_from_raw(Xs, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (once: the ages below start from an empty queue)
     __syncthreads();
+    if (late)
+        for (int i = 0; i < a.ws_tiles; ++i) __builtin_amdgcn_s_sleep(1);  // (64 cycles each)
     int age0 = 0, age1 = 0, age2 = 0;
     if (n_chunks > 1 && !(a.dbg & 1)) {
         load_raw(1);
         age0 = age1 = age2 = raw_ops;
     }
 
+    if constexpr (KT > 0) {
+        // ================= compile-time tap count (the resblock convs: k = 3, 7, 11) ============================
+        // A chunk's KT steps are unrolled, so every ring slot and every transform part has a fixed place in the code:
+        // the NEXT chunk's transform (24 half-units of ~25 vector instructions) is dealt out over the chunk's 8 KT column
+        // tiles behind their MFMAs -- no branch, no second code version (two versions of the loop body made the register
+        // allocator spill the accumulators where they merge; guarded blocks cost more in the rounds without a transform
+        // than they saved in the others).  Tap t of a chunk uses ring slot t % 3; a slot is refilled after its last
+        // use in the chunk with the next chunk's tap of the same slot number, so the ring needs no drain at a boundary.
+        int cur = 0;
+        int ages[3] = {age0, age1, age2};
+        u32x4 ahs[3] = {ah0, ah1, ah2}, als[3] = {al0, al1, al2};
+        half8 fh[3], fl[3];
+        auto load_tile = [&](int t, int n, half8& fhx, half8& flx) __attribute__((always_inline)) {
+            const uint4* xt = Xs + cur * XBUF + h * XWp + r + t * dil + n * 32;
+            fhx = *reinterpret_cast<const half8*>(xt);
+            flx = *reinterpret_cast<const half8*>(xt + 2 * XWp);
+        };
+        load_tile(0, 0, fh[0], fl[0]);
+        load_tile(0, 1, fh[1], fl[1]);
+        constexpr int TILES = NT * KT;
+        // the transform starts once the input prefetch (issued at the chunk's start) has had two steps to land
+        constexpr int I0 = KT >= 5 ? 2 * NT : NT;
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const bool more = ch + 1 < n_chunks;
+            static_for<0, TILES>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;  // tile of the chunk
+                constexpr int t = i / NT, n = i % NT, sl = t % 3;
+                constexpr int e = i % 3, e2 = (i + 2) % 3;
+                if constexpr (n == 0) wait_A(ages[sl], ahs[sl], als[sl]);
+                const half8 ah = __builtin_bit_cast(half8, ahs[sl]), al = __builtin_bit_cast(half8, als[sl]);
+                if constexpr (i + 2 < TILES) load_tile((i + 2) / NT, (i + 2) % NT, fh[e2], fl[e2]);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fh[e], acc[0][n], 0, 0, 0);
+                acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fl[e], acc[0][n], 0, 0, 0);
+                acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fh[e], acc[0][n], 0, 0, 0);
+                // half-units [h0, h1) of the next chunk's transform ride on this tile (in the last chunk they run on
+                // stale registers into the image nobody reads: cheaper than a second version of the loop)
+                constexpr int h0 = i > I0 ? ((i - I0) * 24) / (TILES - I0) : 0;
+                constexpr int h1 = i + 1 > I0 ? ((i + 1 - I0) * 24) / (TILES - I0) : 0;
+                // (no run-time condition around them: a branch would put them in a block of their own, behind the MFMAs
+                // instead of between them)
+                if constexpr (h1 > h0) {
+                    xform_a(h0 / 2, h0 & 1, ch + 1);
+                    xform_b();
+                    xform_c(h0 / 2, h0 & 1, Xs + (cur ^ 1) * XBUF, ch + 1);
+                }
+                if constexpr (h1 > h0 + 1) {
+                    xform_a((h0 + 1) / 2, (h0 + 1) & 1, ch + 1);
+                    xform_b();
+                    xform_c((h0 + 1) / 2, (h0 + 1) & 1, Xs + (cur ^ 1) * XBUF, ch + 1);
+                }
+                static_assert(h1 - h0 <= 2, "at most two half-units per tile");
+                if constexpr (h1 - h0 == 1) {
+#pragma unroll
+                    for (int k3 = 0; k3 < 3; ++k3) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);  // its share of the vector work
+                    }
+                } else if constexpr (h1 - h0 >= 2) {
+#pragma unroll
+                    for (int k3 = 0; k3 < 3; ++k3) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 18, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (n == NT - 1) {
+                    // refill this slot: with the tap three further on, or (its last use in the chunk) with the next
+                    // chunk's tap of the same slot number
+                    const int nxt = t + 3 < KT ? ch * KT + t + 3 : (ch + 1) * KT + sl;
+                    if (t + 3 < KT || (more && sl < KT)) {
+                        load_A(nxt, ahs[sl], als[sl]);
+                        ages[sl] = 0;
+                        ages[(sl + 1) % 3] += 2;
+                        ages[(sl + 2) % 3] += 2;
+                    }
+                }
+            });
+            if (more) {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                cur ^= 1;
+                if (ch + 2 < n_chunks && !(a.dbg & 1)) {
+                    load_raw(ch + 2);
+                    ages[0] += raw_ops;
+                    ages[1] += raw_ops;
+                    ages[2] += raw_ops;
+                }
+                load_tile(0, 0, fh[0], fl[0]);
+                load_tile(0, 1, fh[1], fl[1]);
+            }
+        }
+    } else {
     int cur = 0, ch = 0, tt = 0;
-    half8 bh[2][2], bl[2][2];
-    // B fragments of column tiles (2 q, 2 q + 1) of tap t of the current image: hi at xl, lo two image rows further
-    auto load_B = [&](int t, int q, half8 (&bhx)[2], half8 (&blx)[2]) __attribute__((always_inline)) {
-        const uint4* xt = Xs + cur * XBUF + h * XWp + r + t * dil + q * 64;
-        bhx[0] = *reinterpret_cast<const half8*>(xt);
-        bhx[1] = *reinterpret_cast<const half8*>(xt + 32);
-        blx[0] = *reinterpret_cast<const half8*>(xt + 2 * XWp);
-        blx[1] = *reinterpret_cast<const half8*>(xt + 2 * XWp + 32);
+    // B fragments: a three-entry ring over the column tiles of the walk.  A tile's three MFMAs run back to back on its
+    // accumulator (a_lo b_hi, a_hi b_lo, a_hi b_hi: the per-accumulator order of every other tile shape), so an entry is
+    // free as soon as they are issued and the fragments of the tile two further on are read under them: 24 registers
+    // instead of the 32 of a two-group double buffer, which is what makes room for the transform's temporaries.
+    // 8 tiles per step and 3 entries: the entry of a step's first tile rotates 0, 2, 1 over the three steps of a round.
+    half8 fh[3], fl[3];
+    auto load_tile = [&](int t, int n, half8& fhx, half8& flx) __attribute__((always_inline)) {
+        const uint4* xt = Xs + cur * XBUF + h * XWp + r + t * dil + n * 32;
+        fhx = *reinterpret_cast<const half8*>(xt);
+        flx = *reinterpret_cast<const half8*>(xt + 2 * XWp);
     };
-    load_B(0, 0, bh[0], bl[0]);
-    // one (chunk, tap) step on ring slot (ahx, alx) of age `age`; the other two slots' ages are o1, o2
-    auto step = [&](u32x4& ahx, u32x4& alx, int& age, int& o1, int& o2, int sidx) __attribute__((always_inline)) {
+    load_tile(0, 0, fh[0], fl[0]);
+    load_tile(0, 1, fh[1], fl[1]);
+    // one (chunk, tap) step on ring slot (ahx, alx) of age `age`; the other two slots' ages are o1, o2.
+    // E0: ring entry of the step's first tile, a constant at every call site.
+    auto step = [&](const int E0, u32x4& ahx, u32x4& alx, int& age, int& o1, int& o2, int sidx) __attribute__((always_inline)) {
         wait_A(age, ahx, alx);
         const half8 ah = __builtin_bit_cast(half8, ahx), al = __builtin_bit_cast(half8, alx);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            // the next group's fragments are read under this group's MFMAs (after a tap's last group: the first group of
-            // the next tap; after a chunk's last tap the new image is read behind the barrier below)
-            if (q < 3)
-                load_B(tt, q + 1, bh[(q + 1) & 1], bl[(q + 1) & 1]);
+        for (int n = 0; n < NT; ++n) {
+            const int e = (E0 + n) % 3, e2 = (E0 + n + 2) % 3;
+            // the fragments of the tile two further on (in the next step's tap once this step runs out of tiles; after a
+            // chunk's last tap the new image is read behind the barrier below)
+            if (n + 2 < NT)
+                load_tile(tt, n + 2, fh[e2], fl[e2]);
             else if (tt + 1 < K)
-                load_B(tt + 1, 0, bh[0], bl[0]);
-            // (scheduling barriers: without them the compiler sinks these reads to just before their use, single-buffers
-            // the fragments, and a wave running alone waits out the LDS latency in every group)
+                load_tile(tt + 1, n + 2 - NT, fh[e2], fl[e2]);
+            // (scheduling barriers: without them the compiler sinks the reads to just before their use and a wave running
+            // alone waits out the LDS latency every time)
             __builtin_amdgcn_sched_barrier(0);
-            const int n0 = 2 * q, n1 = 2 * q + 1;
-            // (timing ablations, KX_DBG bits: 1 no input staging, 8 no epilogue)
-            acc[0][n0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[q & 1][0], acc[0][n0], 0, 0, 0);
-            acc[0][n1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[q & 1][1], acc[0][n1], 0, 0, 0);
-            acc[0][n0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[q & 1][0], acc[0][n0], 0, 0, 0);
-            acc[0][n1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[q & 1][1], acc[0][n1], 0, 0, 0);
-            acc[0][n0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[q & 1][0], acc[0][n0], 0, 0, 0);
-            acc[0][n1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[q & 1][1], acc[0][n1], 0, 0, 0);
+            // (the transform stays at the chunk boundary in this form: its parts placed behind these MFMAs in blocks guarded
+            // by a wave-uniform flag were measured 2 % SLOWER than the plain loop -- two taken branches per tile in the
+            // rounds without a transform; the unrolled form above needs no guards)
+            acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fh[e], acc[0][n], 0, 0, 0);
+            acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fl[e], acc[0][n], 0, 0, 0);
+            acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fh[e], acc[0][n], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         // (never past the end: the compiler takes the result of such an asm for dead and available at once, and would
@@ -251,28 +433,35 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
             tt = 0;
             ++ch;
             if (ch < n_chunks) {
-                if (!(a.dbg & 1)) stage_from_raw(Xs + (cur ^ 1) * XBUF, ch);
+                if (a.dbg & 4096) {  // (bit 4096: the loads are waited for and dropped, no transform, no LDS writes)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) asm volatile("" ::"v"(raw[j][c]));
+                } else if (!(a.dbg & 1))
+                    stage_from_raw(Xs + (cur ^ 1) * XBUF, ch);
                 // one barrier per chunk: the image just written becomes readable, and every wave has finished reading
                 // the other one before anybody overwrites it in the NEXT chunk's staging.  Only LDS traffic has to be
                 // complete: the A-ring loads stay in flight across it.
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 cur ^= 1;
-                if (ch + 1 < n_chunks && !(a.dbg & 1)) {
+                if (ch + 1 < n_chunks && !(a.dbg & (1 | 2048))) {  // (bit 2048: the transform runs on stale registers)
                     load_raw(ch + 1);
                     age += raw_ops;
                     o1 += raw_ops;
                     o2 += raw_ops;
                 }
-                load_B(0, 0, bh[0], bl[0]);
+                load_tile(0, 0, fh[(E0 + NT) % 3], fl[(E0 + NT) % 3]);
+                load_tile(0, 1, fh[(E0 + NT + 1) % 3], fl[(E0 + NT + 1) % 3]);
             }
         }
     };
     for (int s3 = 0; s3 < n_steps; s3 += 3) {
-        step(ah0, al0, age0, age1, age2, s3);
-        if (s3 + 1 < n_steps) step(ah1, al1, age1, age2, age0, s3 + 1);
-        if (s3 + 2 < n_steps) step(ah2, al2, age2, age0, age1, s3 + 2);
+        step(0, ah0, al0, age0, age1, age2, s3);
+        if (s3 + 1 < n_steps) step(2, ah1, al1, age1, age2, age0, s3 + 1);
+        if (s3 + 2 < n_steps) step(1, ah2, al2, age2, age0, age1, s3 + 2);
     }
-
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (belt and braces: no hand-counted load is in flight past this point)
     if (a.dbg & 8) return;
     // the statistics scratch of the epilogue lives in the input buffers: everybody must be done reading them
@@ -285,13 +474,24 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
                                            t0 + 128, r, h, ncols, Lout, tile_x * 2 + 1, stat_scr);
 }
 
-template <int ACT>
+template <int ACT, int KT>
 static void launch_da_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
-    auto kern = conv1d_f16x3_da_kernel<ACT>;
+    auto kern = conv1d_f16x3_da_kernel<ACT, KT>;
     constexpr size_t lds = 16 * (size_t)2 * 4 * (256 + 128);  // two input buffers: 48 KiB
     dim3 grid((max_cols + 255) / 256, (a.Cout + 127) / 128, B);
     KX_REQUIRE(grid.x > 0 && grid.y > 0 && grid.y < 65536 && B > 0 && B < 65536, "conv1d f16x3 da: bad grid");
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    static const int phase_delay = getenv("KX_DA_PHASE") ? atoi(getenv("KX_DA_PHASE")) : 0;  // experiment: x 64 cycles
+    if (phase_delay > 0 && !a.stamps) {
+        static unsigned long long* counters = nullptr;
+        if (!counters) KX_HIP(hipMalloc((void**)&counters, 2048 * 8));
+        KX_HIP(hipMemsetAsync(counters, 0, 2048 * 8, s));
+        ConvArgs pa = a;
+        pa.stamps = counters;
+        pa.dbg |= 16384;
+        pa.ws_tiles = phase_delay;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, pa);
+    } else
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     KX_HIP(hipGetLastError());
 }
 
@@ -300,12 +500,18 @@ void launch_conv1d_f16x3_da(const ConvArgs& a, int B, int max_cols, hipStream_t 
     KX_REQUIRE(a.n_chunks16 == (a.Cin + CK16 - 1) / CK16 && a.w16 != nullptr, "conv1d f16x3 da: weights not packed");
     KX_REQUIRE(a.epi != EPI_GELU_NEW, "conv1d f16x3 da: no gelu epilogue");
     if (max_cols <= 0) return;
-    if (a.act == ACT_SNAKE)
-        launch_da_inst<ACT_SNAKE>(a, B, max_cols, s);
-    else if (a.act == ACT_LEAKY)
-        launch_da_inst<ACT_LEAKY>(a, B, max_cols, s);
-    else
-        launch_da_inst<ACT_NONE>(a, B, max_cols, s);
+    // the resblock tap counts get the unrolled form with the transform between the MFMAs (KX_DA_STATIC=0: run-time form)
+    static const int st = getenv("KX_DA_STATIC") ? atoi(getenv("KX_DA_STATIC")) : 1;
+    if (a.act == ACT_SNAKE) {
+        if (st && a.K == 11) launch_da_inst<ACT_SNAKE, 11>(a, B, max_cols, s);
+        else if (st && a.K == 7) launch_da_inst<ACT_SNAKE, 7>(a, B, max_cols, s);
+        else if (st && a.K == 3) launch_da_inst<ACT_SNAKE, 3>(a, B, max_cols, s);
+        else launch_da_inst<ACT_SNAKE, 0>(a, B, max_cols, s);
+    } else if (a.act == ACT_LEAKY) {
+        if (st && a.K == 3) launch_da_inst<ACT_LEAKY, 3>(a, B, max_cols, s);
+        else launch_da_inst<ACT_LEAKY, 0>(a, B, max_cols, s);
+    } else
+        launch_da_inst<ACT_NONE, 0>(a, B, max_cols, s);
 }
 
 }  // namespace kx
