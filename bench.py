@@ -93,7 +93,7 @@ def roofline(f16x3, conv_flops, conv_ms, n_launch, steps, wall, B, T, F, conv_by
         return None
     ach = conv_flops / (conv_ms * 1e-3) / 1e12
     peak = PEAK_F16_MFMA_TFLOPS if f16x3 else PEAK_F32_MFMA_TFLOPS
-    kern = ("kx::conv1d_f16x3_kernel<128,{256|128},2,2,ACT> (f16 32x32x16 MFMA x3, implicit GEMM)" if f16x3
+    kern = ("kx::conv1d_f16x3_da_kernel<ACT,K> + kx::conv1d_f16x3_kernel<128,..> (the 128-row f16x3 conv family: f16 32x32x16 MFMA x3, implicit GEMM)" if f16x3
             else "kx::conv1d_mfma_kernel<128,128,2,2> (f32 32x32x2 MFMA implicit GEMM)")
     traffic = pmc_traffic(B, T, F, "f16x3" if f16x3 else "f32")
     alg_bytes = conv_bytes / max(n_launch, 1)

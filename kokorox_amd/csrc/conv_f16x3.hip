@@ -474,10 +474,21 @@ void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStre
         // k = 1 GEMMs (ALBERT, projections, LSTM input products) take the virtual-tap form; it is also the one
         // kernel whose epilogue carries gelu_new
         if (a.K == 1 && a.stride == 1 && !a.stat_part && !a.in_up2 && a.n_chunks16 >= 3 && a.act != ACT_SNAKE) {
-            if (a.act == ACT_LEAKY)
-                launch_inst16_pf<128, 128, 2, 2, ACT_LEAKY, 3, true, 3>(a, B, max_cols, s);
-            else
-                launch_inst16_pf<128, 128, 2, 2, ACT_NONE, 3, true, 3>(a, B, max_cols, s);
+            // Two 16-channel chunks per super-chunk instead of three: 48 KiB of LDS instead of 73.7, so three workgroups
+            // fit a CU (the registers always allowed three) and the 1040 - 1170 workgroups of the ALBERT GEMMs at batch 64
+            // run in two rounds of 768 instead of three rounds of 512.  (KX_GEMM_VT=3: the former form.)
+            static const int vt = env_int("KX_GEMM_VT", 2);
+            if (vt == 3) {
+                if (a.act == ACT_LEAKY)
+                    launch_inst16_pf<128, 128, 2, 2, ACT_LEAKY, 3, true, 3>(a, B, max_cols, s);
+                else
+                    launch_inst16_pf<128, 128, 2, 2, ACT_NONE, 3, true, 3>(a, B, max_cols, s);
+            } else {
+                if (a.act == ACT_LEAKY)
+                    launch_inst16_pf<128, 128, 2, 2, ACT_LEAKY, 2, true, 2>(a, B, max_cols, s);
+                else
+                    launch_inst16_pf<128, 128, 2, 2, ACT_NONE, 2, true, 2>(a, B, max_cols, s);
+            }
             return;
         }
         KX_REQUIRE(a.epi != EPI_GELU_NEW, "conv1d f16x3: gelu epilogue exists only for k=1 GEMMs with >= 48 input channels");

@@ -311,7 +311,13 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
         load_tile(0, 1, fh[1], fl[1]);
         constexpr int TILES = NT * KT;
         // the transform starts once the input prefetch (issued at the chunk's start) has had two steps to land
-        constexpr int I0 = KT >= 5 ? 2 * NT : NT;
+#ifndef KX_DA_I0_LONG
+#define KX_DA_I0_LONG 5  // steps before the first transform part, k >= 9
+#endif
+#ifndef KX_DA_I0_MID
+#define KX_DA_I0_MID 3   // k = 5 .. 8
+#endif
+        constexpr int I0 = KT >= 9 ? KX_DA_I0_LONG * NT : (KT >= 5 ? KX_DA_I0_MID * NT : NT);
         for (int ch = 0; ch < n_chunks; ++ch) {
             const bool more = ch + 1 < n_chunks;
             static_for<0, TILES>([&](auto ic) __attribute__((always_inline)) {

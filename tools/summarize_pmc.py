@@ -28,7 +28,8 @@ def load(pat):
 def main(fetch_dir, write_dir, out, bench_stdout, family="conv1d_f16x3_kernel<128,", mode="f16x3"):
     f = load(fetch_dir + "/*/*_counter_collection.csv")
     w = load(write_dir + "/*/*_counter_collection.csv")
-    fam = [k for k in f if family in k]  # every instance of the BM=128 family counts as the dominant kernel
+    fams = family.split("|")  # ("a|b": several name patterns, e.g. the direct-A and the LDS-DMA form of the 128-row conv)
+    fam = [k for k in f if any(x in k for x in fams)]  # every instance of the BM=128 family counts as the dominant kernel
     n = sum(f[k][0] for k in fam)
     fetch_kib = sum(f[k][1] for k in fam)
     write_kib = sum(w[k][1] for k in fam)
