@@ -374,6 +374,18 @@ static int env_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
+static int conv16_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        KX_HIP(hipGetDevice(&dev));
+        KX_HIP(hipGetDeviceProperties(&pr, dev));
+        n = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }
+    return n;
+}
+
 template <int BM, int BN, int WM, int WN, int ACT, int TK, bool PF, int VT = 1>
 static void launch_inst16_pf(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
     static size_t lds_limit = 64 * 1024;  // raise the dynamic-LDS limit only as far as a launch needs
@@ -477,7 +489,10 @@ void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStre
             // Two 16-channel chunks per super-chunk instead of three: 48 KiB of LDS instead of 73.7, so three workgroups
             // fit a CU (the registers always allowed three) and the 1040 - 1170 workgroups of the ALBERT GEMMs at batch 64
             // run in two rounds of 768 instead of three rounds of 512.  (KX_GEMM_VT=3: the former form.)
-            static const int vt = env_int("KX_GEMM_VT", 2);
+            // (small grids -- batch 1 -- keep three: fewer barriers per unit of work, and every workgroup is resident anyway)
+            static const int vt_env = env_int("KX_GEMM_VT", 0);
+            const long wgs = (long)((max_cols + 127) / 128) * ((a.Cout + 127) / 128);
+            const int vt = vt_env ? vt_env : (wgs > 2L * conv16_cu_count() ? 2 : 3);
             if (vt == 3) {
                 if (a.act == ACT_LEAKY)
                     launch_inst16_pf<128, 128, 2, 2, ACT_LEAKY, 3, true, 3>(a, B, max_cols, s);

@@ -12,11 +12,19 @@
 // Here wave w owns output rows [32 w, 32 w + 32) of the 128-row tile and ALL 256 columns (1 x 8 accumulator tiles, the
 // same 128 registers as the 2 x 4 split), so the A fragments of a wave are its own: a_hi / a_lo of a (chunk, tap) step
 // are one 16-byte global load each per lane, coalesced (the packed image [chunk][tap][hi|lo][k-half][row][8 ch] puts a
-// wave's 32 rows x 16 B back to back), issued two steps ahead of their use into a three-deep register ring.  Every
-// weight byte is fetched once per workgroup, as before, but through the vector-load path (64 B/clk) and with nothing
-// to wait for at a barrier: the weight-piece buffers, their four barriers per chunk and the A-operand ds_reads are
-// gone; what is left is ONE barrier per 16-channel chunk (the input images alternate between two LDS buffers).
-// B fragments: 16 ds_read_b128 per tap and wave, in four groups of two column tiles read one group ahead.
+// wave's 32 rows x 16 B back to back), issued two to three steps ahead of their use into a three-slot register ring by
+// inline asm with hand-counted s_waitcnt vmcnt (see load_A / wait_A for why the compiler cannot be left to count).
+// Every weight byte is fetched once per workgroup, as before, but through the vector-load path and with nothing to wait
+// for at a barrier: the weight-piece buffers, their four barriers per chunk and the A-operand ds_reads are gone; what is
+// left is ONE barrier per 16-channel chunk (the input images alternate between two LDS buffers).
+// B fragments: a three-entry ring over the column tiles; a tile's three MFMAs run back to back on its accumulator and the
+// fragments of the tile two further on are read under them.
+// Two forms of the main loop:
+//   * compile-time tap count (KT = 3, 7, 11: the resblock convs, 85 % of the conv time): a chunk's KT steps are unrolled and
+//     the NEXT chunk's input transform (AdaIN affine + snake + f16 split, ~600 vector instructions per wave and chunk) is
+//     dealt out in 24 pieces between the MFMAs of the chunk's column tiles, where the matrix pipe hides it; done in one
+//     piece at the chunk boundary it costs exactly its own duration (profiles/r02_da_ablations.txt);
+//   * run-time tap count (KT = 0: polyphase upsamplers, 1-tap projections): three steps per round, transform at the boundary.
 // Per accumulator the products are added in the same order as in conv1d_f16x3_kernel (a_lo b_hi, a_hi b_lo, a_hi b_hi
 // per tap, taps and chunks ascending), and the InstanceNorm partial sums cover the same 128-column groups in the same
 // order, so results are bit-identical to the other tile shapes (batch invariance, tests/test_gpu_forward.py).

@@ -228,3 +228,30 @@ def test_conv1d_epilogue_forms(B, Cin, Cout, L, k, p, d, mode):
     y3, st3 = hk.conv1d_epilogue(x, w, b, pad=p, dil=d, out_mul=float(np.float32(0.70710678)), want_stats=True, mode=mode)
     assert np.abs(y3 - conv * float(np.float32(0.70710678))).max() < 2e-5
     assert np.abs(st3[..., 0] - y3.astype(np.float64).sum(axis=2)).max() < 2e-3 * max(1.0, np.sqrt(Lout) / 10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Cin,Cout,L,k,d", [(8, 128, 128, 20000, 11, 1), (4, 256, 256, 6000, 7, 3), (8, 128, 128, 12000, 3, 5)])
+def test_direct_a_kernel_is_bit_identical_under_load(B, Cin, Cout, L, k, d):
+    """The direct-A kernel (conv_f16x3_da.hip, mode 3) against the LDS-DMA kernel (mode 1), bit for bit, on launches large
+    enough to fill the chip: its weight ring is loaded by inline asm with hand-counted waits, and a fragment used before
+    it has landed only shows when memory is slow (it did: a register copy ahead of the wait, found on exactly this shape)."""
+    from kokorox_amd import hip_koko as hk
+    rng = np.random.default_rng(5 + k)
+    x = rng.standard_normal((B, Cin, L), dtype=np.float32)
+    w = (rng.standard_normal((Cout, Cin, k), dtype=np.float32) / np.sqrt(Cin * k)).astype(np.float32)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    alpha = (0.5 + rng.random(Cin)).astype(np.float32)
+    norm = rng.standard_normal((B, 3, Cin), dtype=np.float32)
+    norm[:, 1] = 1.0 + 0.1 * norm[:, 1]
+    p = d * (k - 1) // 2
+    for kw in (dict(), dict(act=2, alpha=alpha, norm=norm)):
+        y1 = hk.conv1d(x, w, b, pad=p, dil=d, mode=1, **kw)
+        y3 = hk.conv1d(x, w, b, pad=p, dil=d, mode=3, **kw)
+        assert np.isfinite(y3).all()
+        np.testing.assert_array_equal(y1, y3)
+    res = rng.standard_normal(y1.shape, dtype=np.float32)
+    o1 = hk.conv1d_epilogue(x, w, b, pad=p, dil=d, resid=res, want_stats=True, mode=1)
+    o3 = hk.conv1d_epilogue(x, w, b, pad=p, dil=d, resid=res, want_stats=True, mode=3)
+    np.testing.assert_array_equal(o1[0], o3[0])
+    np.testing.assert_array_equal(o1[1], o3[1])
