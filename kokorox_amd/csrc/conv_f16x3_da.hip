@@ -66,19 +66,31 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, ct = blockIdx.y;
-    // XCD-aware column-tile order (as conv1d_f16x3_kernel: the blocks of one XCD get a contiguous range of column tiles)
-    int tile_x = blockIdx.x;
-    if (a.xcd_swizzle && gridDim.x >= 16) {
-        const int nx = gridDim.x;
-        const int off = (int)(((long)nx * (blockIdx.y + (long)gridDim.y * blockIdx.z)) & 7);
-        const int cls = (blockIdx.x + off) & 7;
-        int start = 0;
-        for (int c = 0; c < cls; ++c) {
-            const int first = (c - off) & 7;
-            start += first < nx ? (nx - first + 7) >> 3 : 0;
+    const int b = blockIdx.z;
+    // XCD-aware tile order (as conv1d_f16x3_kernel: workgroups are dealt round-robin over the 8 XCDs by linear block id, and
+    // the blocks of one XCD get a contiguous range of tiles so that the window overlap of neighbouring column tiles is an L2
+    // hit), extended to the row tiles: the tiles of one utterance are ordered (column tile, row tile) with the ROW tile
+    // fastest, so the two row tiles of a 256-channel layer, which stage the same input window, run side by side on one XCD
+    // and the second one's input comes from L2 instead of HBM.
+    int tile_x = blockIdx.x, ct = blockIdx.y;
+    {
+        const int nx = gridDim.x, ny = gridDim.y, N = nx * ny;
+        const int l = blockIdx.x + nx * blockIdx.y;  // linear id inside the utterance's slab (dispatch order)
+        int lp = l;
+        if (a.xcd_swizzle && N >= 16) {
+            const int off = (int)(((long)N * blockIdx.z) & 7);  // XCD class of l = 0 in this slab
+            const int cls = (l + off) & 7;
+            int start = 0;
+            for (int c = 0; c < cls; ++c) {
+                const int first = (c - off) & 7;  // smallest l of class c
+                start += first < N ? (N - first + 7) >> 3 : 0;
+            }
+            lp = start + (l >> 3);  // l = first_cls + 8 j is the j-th block of its class: j = l >> 3 (first < 8)
         }
-        tile_x = start + (blockIdx.x >> 3);
+        if (a.xcd_swizzle) {
+            tile_x = lp / ny;
+            ct = lp - tile_x * ny;
+        }
     }
     const int t0 = tile_x * BN;
     const int Lin = a.in_len.lens[b] * a.in_len.mul + a.in_len.add;
@@ -259,8 +271,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
     // wants is made from that point, after the data has landed.
     auto wait_A = [&](int age, u32x4& a_hi, u32x4& a_lo) __attribute__((always_inline)) {
         if (age >= 60) asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
+        else if (age >= 34) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
         else if (age >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if (age >= 30) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
         else if (age >= 28) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+        else if (age >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if (age >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (age >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -276,22 +291,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
     load_A(1, ah1, al1);
     load_A(2, ah2, al2);
 
-    // (experiment, KX_DBG bit 16384: the second workgroup that ever lands on a CU in this launch starts its main loop late by
-    // a.ws_tiles x 64 cycles, so that the two co-resident workgroups are out of phase; a.stamps doubles as the per-CU counters)
-    int late = 0;
-    if ((a.dbg & 16384) && a.stamps) {
-        const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-        const unsigned cu = ((xcc & 7u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
-        unsigned long long old = 0;
-        if (tid == 0) old = atomicAdd(a.stamps + cu, 1ull);
-        late = __builtin_amdgcn_readfirstlane((int)old) == 1 ? 1 : 0;
-    }
     load_raw(0);
     stage_from_raw(Xs, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (once: the ages below start from an empty queue)
     __syncthreads();
-    if (late)
-        for (int i = 0; i < a.ws_tiles; ++i) __builtin_amdgcn_s_sleep(1);  // (64 cycles each)
     int age0 = 0, age1 = 0, age2 = 0;
     if (n_chunks > 1 && !(a.dbg & 1)) {
         load_raw(1);
@@ -307,8 +310,23 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
         // than they saved in the others).  Tap t of a chunk uses ring slot t % 3; a slot is refilled after its last
         // use in the chunk with the next chunk's tap of the same slot number, so the ring needs no drain at a boundary.
         int cur = 0;
-        int ages[3] = {age0, age1, age2};
-        u32x4 ahs[3] = {ah0, ah1, ah2}, als[3] = {al0, al1, al2};
+        // ring depths: R weight slots (tap t of a chunk uses slot t % R), BR column-tile entries (tile i uses entry i % BR and
+        // is read BR - 1 tiles ahead).  Four weight slots with a two-entry fragment ring need fewer registers than three and
+        // three (244 against 249 for k = 11) and measure the same (23.7 against 23.9 ms on the k = 11 launches): the cost of
+        // the input prefetch that remains (-4.6 ms without it) is not weight loads queued behind it, nor the transform
+        // parts waiting for it (starting them 8 instead of 5 steps into the chunk: no difference), but its traffic.
+#ifndef KX_DA_RING_LONG
+#define KX_DA_RING_LONG 4
+#endif
+        constexpr int R = KT >= 7 ? KX_DA_RING_LONG : 3, BR = R == 4 ? 2 : 3;
+        int ages[4] = {age0, age1, age2, 0};
+        u32x4 ahs[4] = {ah0, ah1, ah2, ah2}, als[4] = {al0, al1, al2, al2};
+        if constexpr (R == 4) {
+            load_A(3, ahs[3], als[3]);
+            ages[0] += 2;
+            ages[1] += 2;
+            ages[2] += 2;
+        }
         half8 fh[3], fl[3];
         auto load_tile = [&](int t, int n, half8& fhx, half8& flx) __attribute__((always_inline)) {
             const uint4* xt = Xs + cur * XBUF + h * XWp + r + t * dil + n * 32;
@@ -316,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
             flx = *reinterpret_cast<const half8*>(xt + 2 * XWp);
         };
         load_tile(0, 0, fh[0], fl[0]);
-        load_tile(0, 1, fh[1], fl[1]);
+        if constexpr (BR == 3) load_tile(0, 1, fh[1], fl[1]);
         constexpr int TILES = NT * KT;
         // the transform starts once the input prefetch (issued at the chunk's start) has had two steps to land
 #ifndef KX_DA_I0_LONG
@@ -330,11 +348,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
             const bool more = ch + 1 < n_chunks;
             static_for<0, TILES>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;  // tile of the chunk
-                constexpr int t = i / NT, n = i % NT, sl = t % 3;
-                constexpr int e = i % 3, e2 = (i + 2) % 3;
+                constexpr int t = i / NT, n = i % NT, sl = t % R;
+                constexpr int e = i % BR, ip = i + BR - 1, e2 = ip % BR;
                 if constexpr (n == 0) wait_A(ages[sl], ahs[sl], als[sl]);
                 const half8 ah = __builtin_bit_cast(half8, ahs[sl]), al = __builtin_bit_cast(half8, als[sl]);
-                if constexpr (i + 2 < TILES) load_tile((i + 2) / NT, (i + 2) % NT, fh[e2], fl[e2]);
+                if constexpr (ip < TILES) load_tile(ip / NT, ip % NT, fh[e2], fl[e2]);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fh[e], acc[0][n], 0, 0, 0);
                 acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fl[e], acc[0][n], 0, 0, 0);
@@ -373,12 +391,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
                 if constexpr (n == NT - 1) {
                     // refill this slot: with the tap three further on, or (its last use in the chunk) with the next
                     // chunk's tap of the same slot number
-                    const int nxt = t + 3 < KT ? ch * KT + t + 3 : (ch + 1) * KT + sl;
-                    if (t + 3 < KT || (more && sl < KT)) {
+                    const int nxt = t + R < KT ? ch * KT + t + R : (ch + 1) * KT + sl;
+                    if (t + R < KT || (more && sl < KT)) {
                         load_A(nxt, ahs[sl], als[sl]);
-                        ages[sl] = 0;
-                        ages[(sl + 1) % 3] += 2;
-                        ages[(sl + 2) % 3] += 2;
+#pragma unroll
+                        for (int o = 0; o < R; ++o) ages[o] = o == sl ? 0 : ages[o] + 2;
                     }
                 }
             });
@@ -387,12 +404,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
                 cur ^= 1;
                 if (ch + 2 < n_chunks && !(a.dbg & 1)) {
                     load_raw(ch + 2);
-                    ages[0] += raw_ops;
-                    ages[1] += raw_ops;
-                    ages[2] += raw_ops;
+#pragma unroll
+                    for (int o = 0; o < R; ++o) ages[o] += raw_ops;
                 }
                 load_tile(0, 0, fh[0], fl[0]);
-                load_tile(0, 1, fh[1], fl[1]);
+                if constexpr (BR == 3) load_tile(0, 1, fh[1], fl[1]);
             }
         }
     } else {
@@ -494,18 +510,7 @@ static void launch_da_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s
     constexpr size_t lds = 16 * (size_t)2 * 4 * (256 + 128);  // two input buffers: 48 KiB
     dim3 grid((max_cols + 255) / 256, (a.Cout + 127) / 128, B);
     KX_REQUIRE(grid.x > 0 && grid.y > 0 && grid.y < 65536 && B > 0 && B < 65536, "conv1d f16x3 da: bad grid");
-    static const int phase_delay = getenv("KX_DA_PHASE") ? atoi(getenv("KX_DA_PHASE")) : 0;  // experiment: x 64 cycles
-    if (phase_delay > 0 && !a.stamps) {
-        static unsigned long long* counters = nullptr;
-        if (!counters) KX_HIP(hipMalloc((void**)&counters, 2048 * 8));
-        KX_HIP(hipMemsetAsync(counters, 0, 2048 * 8, s));
-        ConvArgs pa = a;
-        pa.stamps = counters;
-        pa.dbg |= 16384;
-        pa.ws_tiles = phase_delay;
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, pa);
-    } else
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     KX_HIP(hipGetLastError());
 }
 
