@@ -486,6 +486,11 @@ void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStre
         // k = 1 GEMMs (ALBERT, projections, LSTM input products) take the virtual-tap form; it is also the one
         // kernel whose epilogue carries gelu_new
         if (a.K == 1 && a.stride == 1 && !a.stat_part && !a.in_up2 && a.n_chunks16 >= 3 && a.act != ACT_SNAKE) {
+            // (test hook mode 2 keeps the virtual-tap form below, so that the two can be compared bit for bit)
+            if (a.ws_force != 1 && conv16_use_dag(a, BM)) {
+                launch_conv1d_f16x3_dag(a, B, max_cols, s);
+                return;
+            }
             // Two 16-channel chunks per super-chunk instead of three: 48 KiB of LDS instead of 73.7, so three workgroups
             // fit a CU (the registers always allowed three) and the 1040 - 1170 workgroups of the ALBERT GEMMs at batch 64
             // run in two rounds of 768 instead of three rounds of 512.  (KX_GEMM_VT=3: the former form.)

@@ -43,3 +43,15 @@ for (B, Cin, Cout, L, k, s) in [(1, 256, 128, 3000, 12, 6), (4, 512, 256, 900, 2
     y1 = hk.conv1d(x, w, b, stride=s, pad=(k - s) // 2, transposed=True, mode=1)
     y3 = hk.conv1d(x, w, b, stride=s, pad=(k - s) // 2, transposed=True, mode=3)
     print("transposed", (B, Cin, Cout, L, k, s), "mismatches:", int((y1 != y3).sum()), "max|d|", float(np.abs(y1 - y3).max()))
+
+# k = 1 GEMMs: direct-A GEMM kernel (mode 1, the default) against the virtual-tap LDS-DMA form (mode 2 keeps it)
+for (B, Cin, Cout, L) in [(4, 768, 2048, 2100), (2, 2048, 768, 4000), (8, 640, 2048, 130), (3, 1090, 1024, 845)]:
+    x = rng.standard_normal((B, Cin, L), dtype=np.float32)
+    w = (rng.standard_normal((Cout, Cin, 1), dtype=np.float32) / np.sqrt(Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    for kw in (dict(), dict(act=1, slope=0.2)):
+        y1 = hk.conv1d(x, w, b, mode=1, **kw)
+        y2 = hk.conv1d(x, w, b, mode=2, **kw)
+        ref = np.einsum("oc,bcl->bol", w[:, :, 0].astype(np.float64), np.where(x > 0, x, x * kw.get("slope", 1.0)).astype(np.float64) if kw else x.astype(np.float64)) + b[None, :, None]
+        print("gemm", (B, Cin, Cout, L), "leaky" if kw else "plain", "mismatches vs virtual-tap form:", int((y1 != y2).sum()),
+              "max|d| vs f64:", float(np.abs(y1 - ref).max()))
