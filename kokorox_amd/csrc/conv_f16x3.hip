@@ -514,7 +514,9 @@ void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStre
         KX_REQUIRE(a.epi != EPI_GELU_NEW, "conv1d f16x3: gelu epilogue exists only for k=1 GEMMs with >= 48 input channels");
         int bn, wn;
         conv16_pick_tile(BM, max_cols, B, a.Cout, a.K, a.dil, a.stride, &bn, &wn, a.ws_force);
-        if (bn == 128 && wn == 1)
+        if (bn == 128 && wn == 1 && conv16_use_da(BM, a.K, a.dil, a.stride, a.merge_T > 0) && a.ws_force != 1)
+            launch_conv1d_f16x3_da(a, B, max_cols, s, 128);  // (test hook mode 2 keeps the LDS-DMA form for comparison)
+        else if (bn == 128 && wn == 1)
             launch_inst16<128, 128, 4, 1>(a, B, max_cols, s);
         else if (bn == 128)
             launch_inst16<128, 128, 2, 2>(a, B, max_cols, s);

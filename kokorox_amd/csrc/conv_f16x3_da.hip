@@ -53,9 +53,11 @@ bool conv16_use_da(int BM, int K, int dil, int stride, int merged) {
     return on && conv16_da_eligible(BM, K, dil, stride, merged);
 }
 
-template <int ACT, int KT>
-__global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs a) {
-    constexpr int BM = 128, BN = 256, NT = 8;
+template <int ACT, int KT, int NTT>
+__global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(const ConvArgs a) {
+    // NTT = 8: the 128 x 256 tile of chip-filling launches; NTT = 4: 128 x 128 for small grids (batch 1), three workgroups per CU
+    constexpr int BM = 128, NT = NTT, BN = 32 * NT;
+    constexpr int HU = (BN + 128) / 128 * 8;  // elements per lane and chunk = half-units of the interleaved transform
     constexpr int XWp = BN + 128;           // window pitch of one image row (columns)
     constexpr int XBUF = 4 * XWp;           // uint4 per input buffer: [hi|lo][octet][XWp]
     constexpr int tap_units = 4 * BM;       // uint4 per (chunk, tap) of the packed weights: [hi|lo][k-half][BM]
@@ -275,6 +277,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
         else if (age >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else if (age >= 30) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
         else if (age >= 28) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+        else if (age >= 26) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+        else if (age >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (age >= 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+        else if (age >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else if (age >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else if (age >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if (age >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (age >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" : "+v"(a_hi), "+v"(a_lo));
     };
-    const int raw_ops = 24 + (has_norm ? 3 : 0) + (ACT == ACT_SNAKE ? 1 : 0);  // vector loads of one load_raw()
+    const int raw_ops = HU + (has_norm ? 3 : 0) + (ACT == ACT_SNAKE ? 1 : 0);  // vector loads of one load_raw()
     // Three-deep A ring with STATIC slots: step s uses slot s % 3 and refills it for step s + 3 as soon as its MFMAs are
     // issued, so a fragment is requested two whole steps before its use and nothing ever moves between registers.  The
     // (chunk, tap) walk is flattened and unrolled by three for that.
@@ -359,8 +366,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
                 acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fh[e], acc[0][n], 0, 0, 0);
                 // half-units [h0, h1) of the next chunk's transform ride on this tile (in the last chunk they run on
                 // stale registers into the image nobody reads: cheaper than a second version of the loop)
-                constexpr int h0 = i > I0 ? ((i - I0) * 24) / (TILES - I0) : 0;
-                constexpr int h1 = i + 1 > I0 ? ((i + 1 - I0) * 24) / (TILES - I0) : 0;
+                constexpr int h0 = i > I0 ? ((i - I0) * HU) / (TILES - I0) : 0;
+                constexpr int h1 = i + 1 > I0 ? ((i + 1 - I0) * HU) / (TILES - I0) : 0;
                 // (no run-time condition around them: a branch would put them in a block of their own, behind the MFMAs
                 // instead of between them)
                 if constexpr (h1 > h0) {
@@ -488,8 +495,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
     };
     for (int s3 = 0; s3 < n_steps; s3 += 3) {
         step(0, ah0, al0, age0, age1, age2, s3);
-        if (s3 + 1 < n_steps) step(2, ah1, al1, age1, age2, age0, s3 + 1);
-        if (s3 + 2 < n_steps) step(1, ah2, al2, age2, age0, age1, s3 + 2);
+        if (s3 + 1 < n_steps) step(NT % 3, ah1, al1, age1, age2, age0, s3 + 1);
+        if (s3 + 2 < n_steps) step((2 * NT) % 3, ah2, al2, age2, age0, age1, s3 + 2);
     }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (belt and braces: no hand-counted load is in flight past this point)
@@ -497,40 +504,57 @@ __global__ __launch_bounds__(256, 2) void conv1d_f16x3_da_kernel(const ConvArgs 
     // the statistics scratch of the epilogue lives in the input buffers: everybody must be done reading them
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     float2* stat_scr = reinterpret_cast<float2*>(smem16) + wave * (32 * 33);
-    // two halves of four column tiles = the 128-column statistics groups of the other tile shapes
-    conv_store_tile<1, 4, EPI_ROWS, false>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][0]), a.w_unscale, b, ct * BM + wave * 32, t0, r,
-                                           h, ncols, Lout, tile_x * 2, stat_scr);
-    conv_store_tile<1, 4, EPI_ROWS, false>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][4]), a.w_unscale, b, ct * BM + wave * 32,
-                                           t0 + 128, r, h, ncols, Lout, tile_x * 2 + 1, stat_scr);
+    // 128-column groups of four column tiles = the statistics groups of the other tile shapes
+    if constexpr (NT == 8) {
+        conv_store_tile<1, 4, EPI_ROWS, false>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][0]), a.w_unscale, b, ct * BM + wave * 32,
+                                               t0, r, h, ncols, Lout, tile_x * 2, stat_scr);
+        conv_store_tile<1, 4, EPI_ROWS, false>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][4]), a.w_unscale, b, ct * BM + wave * 32,
+                                               t0 + 128, r, h, ncols, Lout, tile_x * 2 + 1, stat_scr);
+    } else {
+        conv_store_tile<1, 4, EPI_ROWS, false>(a, acc, a.w_unscale, b, ct * BM + wave * 32, t0, r, h, ncols, Lout, tile_x, stat_scr);
+    }
 }
 
-template <int ACT, int KT>
+template <int ACT, int KT, int NTT>
 static void launch_da_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
-    auto kern = conv1d_f16x3_da_kernel<ACT, KT>;
-    constexpr size_t lds = 16 * (size_t)2 * 4 * (256 + 128);  // two input buffers: 48 KiB
-    dim3 grid((max_cols + 255) / 256, (a.Cout + 127) / 128, B);
+    auto kern = conv1d_f16x3_da_kernel<ACT, KT, NTT>;
+    constexpr int BN = 32 * NTT;
+    // two input buffers (48 / 32 KiB), and never less than the statistics scratch of the epilogue (4 waves x 8.25 KiB)
+    constexpr size_t lds_x = 16 * (size_t)2 * 4 * (BN + 128), lds_scr = 4 * 32 * 33 * sizeof(float2);
+    constexpr size_t lds = lds_x > lds_scr ? lds_x : lds_scr;
+    dim3 grid((max_cols + BN - 1) / BN, (a.Cout + 127) / 128, B);
     KX_REQUIRE(grid.x > 0 && grid.y > 0 && grid.y < 65536 && B > 0 && B < 65536, "conv1d f16x3 da: bad grid");
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     KX_HIP(hipGetLastError());
 }
 
-void launch_conv1d_f16x3_da(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
-    KX_REQUIRE(conv16_da_eligible(128, a.K, a.dil, a.stride, a.merge_T > 0), "conv1d f16x3 da: launch not eligible");
-    KX_REQUIRE(a.n_chunks16 == (a.Cin + CK16 - 1) / CK16 && a.w16 != nullptr, "conv1d f16x3 da: weights not packed");
-    KX_REQUIRE(a.epi != EPI_GELU_NEW, "conv1d f16x3 da: no gelu epilogue");
-    if (max_cols <= 0) return;
+template <int NTT>
+static void launch_da_ntt(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
     // the resblock tap counts get the unrolled form with the transform between the MFMAs (KX_DA_STATIC=0: run-time form)
     static const int st = getenv("KX_DA_STATIC") ? atoi(getenv("KX_DA_STATIC")) : 1;
     if (a.act == ACT_SNAKE) {
-        if (st && a.K == 11) launch_da_inst<ACT_SNAKE, 11>(a, B, max_cols, s);
-        else if (st && a.K == 7) launch_da_inst<ACT_SNAKE, 7>(a, B, max_cols, s);
-        else if (st && a.K == 3) launch_da_inst<ACT_SNAKE, 3>(a, B, max_cols, s);
-        else launch_da_inst<ACT_SNAKE, 0>(a, B, max_cols, s);
+        if (st && a.K == 11) launch_da_inst<ACT_SNAKE, 11, NTT>(a, B, max_cols, s);
+        else if (st && a.K == 7) launch_da_inst<ACT_SNAKE, 7, NTT>(a, B, max_cols, s);
+        else if (st && a.K == 3) launch_da_inst<ACT_SNAKE, 3, NTT>(a, B, max_cols, s);
+        else launch_da_inst<ACT_SNAKE, 0, NTT>(a, B, max_cols, s);
     } else if (a.act == ACT_LEAKY) {
-        if (st && a.K == 3) launch_da_inst<ACT_LEAKY, 3>(a, B, max_cols, s);
-        else launch_da_inst<ACT_LEAKY, 0>(a, B, max_cols, s);
+        if (st && a.K == 3) launch_da_inst<ACT_LEAKY, 3, NTT>(a, B, max_cols, s);
+        else launch_da_inst<ACT_LEAKY, 0, NTT>(a, B, max_cols, s);
     } else
-        launch_da_inst<ACT_NONE, 0>(a, B, max_cols, s);
+        launch_da_inst<ACT_NONE, 0, NTT>(a, B, max_cols, s);
+}
+
+// bn: 256 (chip-filling launches) or 128 (small grids); the statistics slots are 128 columns wide either way
+void launch_conv1d_f16x3_da(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn) {
+    KX_REQUIRE(conv16_da_eligible(128, a.K, a.dil, a.stride, a.merge_T > 0), "conv1d f16x3 da: launch not eligible");
+    KX_REQUIRE(a.n_chunks16 == (a.Cin + CK16 - 1) / CK16 && a.w16 != nullptr, "conv1d f16x3 da: weights not packed");
+    KX_REQUIRE(a.epi != EPI_GELU_NEW, "conv1d f16x3 da: no gelu epilogue");
+    KX_REQUIRE(bn == 256 || bn == 128, "conv1d f16x3 da: tile of 256 or 128 columns");
+    if (max_cols <= 0) return;
+    if (bn == 256)
+        launch_da_ntt<8>(a, B, max_cols, s);
+    else
+        launch_da_ntt<4>(a, B, max_cols, s);
 }
 
 }  // namespace kx

@@ -128,7 +128,7 @@ void launch_conv1d_f16x3_ws(const ConvArgs& a, int B, int max_cols, hipStream_t 
 // conv_f16x3_da.hip: the 128 x 256 tile with the weight fragments loaded from global memory straight into registers
 bool conv16_use_da(int BM, int K, int dil, int stride, int merged);       // eligible AND switched on (default; KX_DA=0 turns it off)
 bool conv16_da_eligible(int BM, int K, int dil, int stride, int merged);  // shape fits the kernel
-void launch_conv1d_f16x3_da(const ConvArgs& a, int B, int max_cols, hipStream_t s);
+void launch_conv1d_f16x3_da(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn = 256);
 // conv_f16x3_dag.hip: k = 1 GEMMs (incl. the merged token-axis form) in the direct-A form, 128 x 128 tile
 bool conv16_use_dag(const ConvArgs& a, int BM);       // eligible AND switched on (default; KX_DAG=0 turns it off)
 bool conv16_dag_eligible(const ConvArgs& a, int BM);
