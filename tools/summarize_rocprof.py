@@ -30,7 +30,7 @@ def main(prof_dir, bench_json, out):
                   f"{r['gflop_per_launch']:.1f} GFLOP/launch -> {r['achieved']:.1f} TFLOP/s = {r['frac'] * 100:.1f}% of "
                   f"{r['peak']} TFLOP/s (dense MFMA peak of the kernel's dtype)"]
         fam = [x for x in rows if "conv1d_mfma_kernel<128, 128, 2, 2>" in x["Name"]
-               or "conv1d_f16x3_kernel<128," in x["Name"] or "conv1d_f16x3_da_kernel<" in x["Name"]]
+               or "conv1d_f16x3_kernel<128," in x["Name"] or "conv1d_f16x3_da_kernel<" in x["Name"] or "conv1d_f16x3_dag_kernel<" in x["Name"]]
         if fam:
             calls = sum(int(x["Calls"]) for x in fam)
             tot_ns = sum(float(x["TotalDurationNs"]) for x in fam)
