@@ -295,8 +295,25 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const float* x, long bs, 
     const int L = len_of(len, b);
     const float* row = x + b * bs + (long)c * ld;
     double s = 0.0, q = 0.0;
-    for (int t = threadIdx.x; t < L; t += 256) {
-        const double v = (double)row[t];
+    // 16-byte loads, two in flight per thread (rows start on 128-byte lines: ld is a multiple of 32 floats); the tail of the
+    // row goes element by element
+    const int L4 = L & ~3;
+    const float4* row4 = reinterpret_cast<const float4*>(row);
+    int t = threadIdx.x;
+    for (; 4 * (t + 256) < L4; t += 512) {
+        const float4 u = row4[t], w = row4[t + 256];
+        const double a0 = u.x, a1 = u.y, a2 = u.z, a3 = u.w, b0 = w.x, b1 = w.y, b2 = w.z, b3 = w.w;
+        s += ((a0 + a1) + (a2 + a3)) + ((b0 + b1) + (b2 + b3));
+        q += ((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) + ((b0 * b0 + b1 * b1) + (b2 * b2 + b3 * b3));
+    }
+    for (; 4 * t < L4; t += 256) {
+        const float4 u = row4[t];
+        const double a0 = u.x, a1 = u.y, a2 = u.z, a3 = u.w;
+        s += (a0 + a1) + (a2 + a3);
+        q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+    for (int e = L4 + threadIdx.x; e < L; e += 256) {
+        const double v = (double)row[e];
         s += v;
         q += v * v;
     }
