@@ -132,12 +132,19 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         xoff[j] = pi;
     }
     const int cmax_in = a.Cin - 1;
+    // (the three InstanceNorm parameter loads are UNCONDITIONAL -- without a norm they read the first input row and are
+    // discarded -- so that a prefetch batch is the same number of vector loads whatever the launch: wait_A counts them, and
+    // tests/test_asm_audit_cpu.py checks the count in the generated code)
+    const float* nm_src = has_norm ? a.nmean + (long)b * a.n_bs : xb;
+    const float* ns_src = has_norm ? a.nscale + (long)b * a.n_bs : xb;
+    const float* nh_src = has_norm ? a.nshift + (long)b * a.n_bs : xb;
     auto load_params = [&](int ch, float (&pv)[4]) __attribute__((always_inline)) {
         const int c = ch * CK16 + g * 8 + (lane & 7);
         const int cc = c < cmax_in ? c : cmax_in;
-        pv[0] = has_norm ? a.nmean[(long)b * a.n_bs + cc] : 0.f;
-        pv[1] = has_norm ? a.nscale[(long)b * a.n_bs + cc] : 1.f;
-        pv[2] = has_norm ? a.nshift[(long)b * a.n_bs + cc] : 0.f;
+        const float m = nm_src[cc], sc = ns_src[cc], sh = nh_src[cc];
+        pv[0] = has_norm ? m : 0.f;
+        pv[1] = has_norm ? sc : 1.f;
+        pv[2] = has_norm ? sh : 0.f;
         pv[3] = (ACT == ACT_SNAKE) ? a.alpha[cc] : 1.f;  // (its reciprocal is taken when the chunk is transformed: a
                                                           // division here would wait for the load on the spot)
     };
@@ -289,7 +296,9 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" : "+v"(a_hi), "+v"(a_lo));
     };
-    const int raw_ops = HU + (has_norm ? 3 : 0) + (ACT == ACT_SNAKE ? 1 : 0);  // vector loads of one load_raw()
+    // vector loads of one load_raw(): exact counting is worth 2 % of the step against counting the asm loads only (always
+    // a safe under-estimate: 123.8 vs 126.2 ms)
+    constexpr int raw_ops = HU + 3 + (ACT == ACT_SNAKE ? 1 : 0);
     // Three-deep A ring with STATIC slots: step s uses slot s % 3 and refills it for step s + 3 as soon as its MFMAs are
     // issued, so a fragment is requested two whole steps before its use and nothing ever moves between registers.  The
     // (chunk, tap) walk is flattened and unrolled by three for that.
@@ -530,6 +539,11 @@ static void launch_da_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s
 
 template <int NTT>
 static void launch_da_ntt(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
+#ifdef KX_DA_AUDIT  // (tests/test_asm_audit_cpu.py compiles just these two instantiations to assembly)
+    if (a.act == ACT_SNAKE) launch_da_inst<ACT_SNAKE, 11, 8>(a, B, max_cols, s);
+    else launch_da_inst<ACT_LEAKY, 0, 4>(a, B, max_cols, s);
+    return;
+#endif
     // the resblock tap counts get the unrolled form with the transform between the MFMAs (KX_DA_STATIC=0: run-time form)
     static const int st = getenv("KX_DA_STATIC") ? atoi(getenv("KX_DA_STATIC")) : 1;
     if (a.act == ACT_SNAKE) {
