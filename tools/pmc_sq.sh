@@ -14,4 +14,4 @@ for grp in \
   echo "pass $i done"
 done
 cd $R
-python tools/summarize_pmc_sq.py gpurun_out/pmc_sq_ "conv1d_f16x3_kernel<128, 256, 2, 2, 2, 3, true, 1>"
+python tools/summarize_pmc_sq.py gpurun_out/pmc_sq_ "${1:-conv1d_f16x3_da_kernel<2, 11, 8>}"
