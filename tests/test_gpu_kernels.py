@@ -255,3 +255,21 @@ def test_direct_a_kernel_is_bit_identical_under_load(B, Cin, Cout, L, k, d):
     o3 = hk.conv1d_epilogue(x, w, b, pad=p, dil=d, resid=res, want_stats=True, mode=3)
     np.testing.assert_array_equal(o1[0], o3[0])
     np.testing.assert_array_equal(o1[1], o3[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Cin,Cout,L", [(4, 768, 2048, 2100), (8, 640, 2048, 130), (3, 1090, 1024, 845), (2, 50, 256, 300)])
+def test_direct_a_gemm_is_bit_identical_to_virtual_tap_form(B, Cin, Cout, L):
+    """k = 1 GEMMs: conv_f16x3_dag.hip (the default) against the virtual-tap LDS-DMA form (test-hook mode 2 keeps it), bit for
+    bit, incl. channel counts that leave a partial 16-channel chunk and a partial three-chunk super-chunk; and against f64."""
+    from kokorox_amd import hip_koko as hk
+    rng = np.random.default_rng(Cin)
+    x = rng.standard_normal((B, Cin, L), dtype=np.float32)
+    w = (rng.standard_normal((Cout, Cin, 1), dtype=np.float32) / np.sqrt(Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    for kw, act in ((dict(), lambda v: v), (dict(act=1, slope=0.2), lambda v: np.where(v > 0, v, 0.2 * v))):
+        y1 = hk.conv1d(x, w, b, mode=1, **kw)
+        y2 = hk.conv1d(x, w, b, mode=2, **kw)
+        np.testing.assert_array_equal(y1, y2)
+        ref = np.einsum("oc,bcl->bol", w[:, :, 0].astype(np.float64), act(x.astype(np.float64))) + b[None, :, None]
+        assert np.abs(y1 - ref).max() < 2e-5
