@@ -71,7 +71,7 @@ def pmc_traffic(B, T, F, mode):
     (profiles/*pmc_conv_traffic.json, written by tools/summarize_pmc.py for this same workload);
     None when no pass matches.  PMC passes cannot run inside this process."""
     import glob
-    best = None
+    best, src = None, None
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_conv_traffic*.json"))):
         try:
             d = json.load(open(p))
@@ -79,8 +79,8 @@ def pmc_traffic(B, T, F, mode):
             continue
         w = d.get("workload", {})
         if (w.get("batch"), w.get("tokens"), w.get("frames"), w.get("conv_mode", "f32")) == (B, T, F, mode):
-            best = d
-    return None if best is None else best["traffic_bytes_per_launch"]
+            best, src = d, os.path.relpath(p, ROOT)
+    return (None, None) if best is None else (best["traffic_bytes_per_launch"], src)
 
 
 def roofline(f16x3, conv_flops, conv_ms, n_launch, steps, wall, B, T, F, conv_bytes=0.0):
@@ -95,10 +95,12 @@ def roofline(f16x3, conv_flops, conv_ms, n_launch, steps, wall, B, T, F, conv_by
     peak = PEAK_F16_MFMA_TFLOPS if f16x3 else PEAK_F32_MFMA_TFLOPS
     kern = ("kx::conv1d_f16x3_da_kernel<ACT,K> + kx::conv1d_f16x3_kernel<128,..> (the 128-row f16x3 conv family: f16 32x32x16 MFMA x3, implicit GEMM)" if f16x3
             else "kx::conv1d_mfma_kernel<128,128,2,2> (f32 32x32x2 MFMA implicit GEMM)")
-    traffic = pmc_traffic(B, T, F, "f16x3" if f16x3 else "f32")
+    traffic, traffic_src = pmc_traffic(B, T, F, "f16x3" if f16x3 else "f32")
     alg_bytes = conv_bytes / max(n_launch, 1)
     out = {"bound": "mfma", "kernel": kern, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
            "traffic": traffic,
+           # (not measured by this run: PMC passes cannot run inside the process; the value is the committed pass below)
+           "traffic_source": f"committed rocprofv3 --pmc pass {traffic_src} (tools/summarize_pmc.py)" if traffic_src else None,
            # algorithmic HBM bytes per launch (each conv reads its input, its residual / running sum
            # where the epilogue uses them and its weights once, and writes its output once; logged per launch by the
            # library) and how much more the PMC counters saw: > 1 = re-reads (window overlap, one staging per row tile)
@@ -140,6 +142,159 @@ def cpu_baseline(blob_path: str, n_utts: int, n_phonemes: int, pinned):
             "utt_per_s": n_utts / wall}
 
 
+def serve_leg(models, n_clients=32, per_client=4, max_batch=64, max_wait_us=3000):
+    """BASELINE configs[4] (kokorox-openai/src/lib.rs:370-439): concurrent clients with mixed voices, incl. the mix
+    "af_sky.4+af_nicole.5" named into the device voice table, over one dispatcher in front of `models` (one per GPU).
+    Returns p50 / p99 latency, aggregate RTF and the batch statistics."""
+    import threading
+    from kokorox_amd import hip_koko as hk
+    from kokorox_amd import weights as W
+    tab = W.synthetic_voices(4)  # af_sky, af_nicole, am_adam, bf_emma
+    for m in models:
+        m.set_pinned_durations(None)
+        m.set_utterance_base(0)
+        m.set_voice_table(tab)
+    rules = [0, 1, [(0, 4.0), (1, 5.0)], 2, [(3, 7.0), (0, 3.0)]]
+    d = hk.Dispatcher(models, max_batch=max_batch, max_wait_us=max_wait_us)
+    rng = np.random.default_rng(0)
+    plan = [[(int(rng.integers(20, 129)), int(rng.integers(0, len(rules))), int(rng.integers(0, 3)), int(rng.integers(1, 2 ** 31)))
+             for _ in range(per_client)] for _ in range(n_clients)]
+    # untimed: one full-length request per model so that the arenas exist at the largest shape
+    for _ in models:
+        d.submit_ex(np.array([0] + [5] * 128 + [0], dtype=np.int64), voices=0, seed=1)
+    lat, audio, errs = [], [], []
+    lock = threading.Lock()
+
+    def client(c):
+        r = np.random.default_rng(100 + c)
+        try:
+            for (k, rule, fmt, seed) in plan[c]:
+                ids = np.concatenate([[0], r.integers(1, 178, size=k), [0]]).astype(np.int64)
+                t = time.perf_counter()
+                w = d.submit_ex(ids, voices=rules[rule], seed=seed, fmt=fmt)
+                dt = time.perf_counter() - t
+                with lock:
+                    lat.append(dt)
+                    audio.append(w.shape[0] / 24000.0)
+        except Exception as e:  # pragma: no cover
+            errs.append(repr(e))
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=client, args=(c,)) for c in range(n_clients)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    st = d.stats()
+    d.close()
+    if errs or not lat:
+        return {"error": errs[:3]}
+    lat = np.sort(np.array(lat))
+    return {"clients": n_clients, "requests": int(len(lat)), "models": len(models), "wall_s": wall,
+            "audio_s": float(np.sum(audio)), "aggregate_rtf": float(np.sum(audio) / wall),
+            "latency_p50_ms": float(lat[len(lat) // 2] * 1e3), "latency_p99_ms": float(lat[int(len(lat) * 0.99)] * 1e3),
+            "requests_per_s": len(lat) / wall, "batches": st["batches"] - len(models), "max_batch": st["max_batch"],
+            "batches_per_model": st["batches_per_model"],
+            "workload": "20..128-phoneme requests, five voice rules (three single voices, af_sky.4+af_nicole.5, "
+                        "bf_emma.7+af_sky.3) through the device voice table, f32 mono / f32 stereo / PCM16 mixed, free-running "
+                        "durations, noise on"}
+
+
+def replicas_main(a):
+    """Single-process form of the N-GPU run (`--replicas N`): kx_create_replicas reads the weight file once and fans the
+    blob out over xGMI inside the library (the reference's server shape: one process holding every GPU), then one host
+    thread per model steps its own utterances.  Same JSON keys as the torchrun form; `weight_broadcast_s` = the fan-out."""
+    import threading
+    import torch
+    from kokorox_amd import hip_koko as hk
+    from kokorox_amd import weights as W
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    ids_env = os.environ.get("KX_REPLICA_IDS")  # e.g. "0,0": rehearse two replicas on a one-GPU box
+    dev_ids = [int(v) for v in ids_env.split(",")] if ids_env else list(range(a.replicas))
+    N = len(dev_ids)
+    if max(dev_ids) >= torch.cuda.device_count():
+        raise SystemExit(f"--replicas {N} but only {torch.cuda.device_count()} GPU(s) visible")
+    progress("preparing synthetic weight blob")
+    blob_path = W.ensure_synthetic_blob()
+    t0 = time.perf_counter()
+    models = hk.HipKoko.replicas(blob_path, dev_ids)
+    t_fan = time.perf_counter() - t0
+    progress(f"{N} replicas ready ({t_fan:.2f} s incl. the one file read)")
+    B, T = a.batch, a.phonemes + 2
+    pinned = np.array([3, 3, 3, 4] * ((T + 3) // 4), dtype=np.int64)[:T]
+    F = int(pinned.sum())
+    audio_ld = 600 * F
+    lens = np.full(B, T, dtype=np.int32)
+    speeds = np.ones(1, dtype=np.float32)
+    voices = W.synthetic_voices(4)
+    state = []
+    for r, (m, di) in enumerate(zip(models, dev_ids)):
+        dev = torch.device("cuda", di)
+        ids = torch.from_numpy(synthetic_ids(B, a.phonemes, seed=1000 + r)).to(dev)
+        styles = torch.from_numpy(np.stack([voices[(r * B + b) % 4, a.phonemes, 0] for b in range(B)])).to(dev)
+        audio = torch.empty((B, audio_ld), dtype=torch.float32, device=dev)
+        frames = torch.zeros(B, dtype=torch.int32, device=dev)
+        m.set_utterance_base(r * B)
+        m.set_pinned_durations([3, 3, 3, 4])
+        state.append((m, ids, styles, audio, frames))
+    torch.cuda.synchronize()
+    bar = threading.Barrier(N + 1)
+    errs = []
+
+    def worker(r):
+        m, ids, styles, audio, frames = state[r]
+        try:
+            for _ in range(a.warmup):
+                m.infer_device(ids.data_ptr(), T, lens, styles.data_ptr(), speeds, audio.data_ptr(), audio_ld, frames.data_ptr(), seed=2)
+                m.sync()
+            bar.wait()  # start of the timed region
+            for _ in range(a.steps):
+                m.infer_device(ids.data_ptr(), T, lens, styles.data_ptr(), speeds, audio.data_ptr(), audio_ld, frames.data_ptr(), seed=2)
+            m.sync()
+            bar.wait()  # end: every replica has finished its K steps
+        except Exception as e:  # pragma: no cover
+            errs.append(repr(e))
+            bar.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(N)]
+    for t in th:
+        t.start()
+    bar.wait()
+    t0 = time.perf_counter()
+    bar.wait()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    for t in th:
+        t.join()
+    if errs:
+        raise SystemExit(f"replica failed: {errs[0]}")
+    for (m, ids, styles, audio, frames) in state:
+        assert (frames.cpu().numpy() == F).all()
+    finite = all(bool(torch.isfinite(s[3][:, : 600 * F]).all().item()) for s in state)
+    audio_s_per_step = N * B * F * 600 / 24000.0
+    f16x3 = models[0].get_conv_mode() == 1
+    out = {
+        "metric": f"real-time factor (audio-s/wall-s), 24 kHz, batch={B}",
+        "value": audio_s_per_step * a.steps / wall, "unit": "x realtime", "n_gpus": N, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (f16x3 split MFMA: 3 f16 MFMAs per product on hi/lo halves, f32 accumulate)" if f16x3 else "f32",
+        "data": "synthetic (seeded random-init Kokoro-82M weights, uniform phoneme ids, N(0,0.1) voice rows)",
+        "config": {"workload": f"batch={B}/GPU synthetic {a.phonemes}-phoneme utterances (T={T}), durations pinned "
+                               f"3,3,3,4 -> F={F} frames = {F * 600 / 24000.0:.2f} s each, noise on, inputs in HBM",
+                   "batch_per_gpu": B, "tokens": T, "frames": F,
+                   "parallelism": f"utterance-sharded x{N}, single process: kx_create_replicas (one file read, peer fan-out), "
+                                  f"one host thread per model, device ids {dev_ids}"},
+        "utterances_per_s": N * B * a.steps / wall, "audio_s_per_step": audio_s_per_step, "finite": finite,
+        "weight_broadcast_s": t_fan, "roofline": None, "cpu_baseline": None,
+        "serve": serve_leg(models) if a.serve else None,
+    }
+    print(json.dumps(out), flush=True)
+    for m in models:
+        m.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,7 +306,12 @@ def main():
     ap.add_argument("--detail", default="", help="write a per-shape table of the conv launches to this file")
     ap.add_argument("--free-run", type=int, default=1, help="also time one step with predicted durations")
     ap.add_argument("--pcie", type=int, default=1, help="also time one step through the host-buffer boundary (N=1)")
+    ap.add_argument("--serve", type=int, default=1, help="also run the 32-client serving leg (configs[4]) on rank 0 at N=1")
+    ap.add_argument("--replicas", type=int, default=0,
+                    help="single-process form: N models from kx_create_replicas, one host thread each (instead of torchrun)")
     a = ap.parse_args()
+    if a.replicas > 0:
+        return replicas_main(a)
 
     import faulthandler
     faulthandler.dump_traceback_later(300, repeat=True, file=sys.stderr)
@@ -353,6 +513,7 @@ def main():
             "free_running": free,
             "pcie_inclusive": pcie,
         }
+        out["serve"] = serve_leg([model]) if (world == 1 and a.serve) else None
         if world == 1 and a.cpu_utts > 0:
             out["cpu_baseline"] = cpu_baseline(blob_path, a.cpu_utts, a.phonemes, pinned)
         else:

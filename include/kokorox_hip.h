@@ -137,12 +137,20 @@ int kx_get_conv_mode(kx_model* m);
 int kx_set_stft_variant(kx_model* m, int variant);
 int kx_get_stft_variant(kx_model* m);
 
+/* Streams ("lanes") of the back half: 1 = every launch on the model's one stream; 4 = the harmonic-source / noise path
+ * and the three resblock chains of each generator stage are issued on streams of their own and meet through events;
+ * 0 (default) = 4 for batches of up to 16 utterances, where launches leave CUs idle (batch 1: 13.8 -> 12.3 ms), else 1.
+ * Results are bit-identical for every value: only the last conv of a chain touches the shared running sum, in a fixed
+ * order.  Env KX_LANES at create. */
+int kx_set_lanes(kx_model* m, int n_lanes);
+
 /* First utterance index used for the noise stream of the next calls (default 0). */
 int kx_set_utterance_base(kx_model* m, uint64_t utt_base);
 
 /* Per-kernel-class HIP-event timing on the model's stream (bench.py roofline leg).
- * While enabled every launch of the dominant kernel, conv1d_mfma_kernel<128,128,2,2>, is
- * bracketed by events on the model's stream.
+ * While enabled every launch of the dominant kernel family -- the 128-row conv / GEMM kernels: conv1d_f16x3_da_kernel,
+ * conv1d_f16x3_dag_kernel and conv1d_f16x3_kernel<128,..> (conv1d_mfma_kernel<128,128,2,2> in f32 mode) -- is
+ * bracketed by events on the stream it is issued on.
  * kx_profile_read drains them: launches, summed milliseconds and summed algorithmic
  * FLOPs (2*Cout*Cin*k*columns per launch) since the last read. */
 int kx_profile_enable(kx_model* m, int on);
@@ -208,7 +216,20 @@ kx_dispatcher* kx_dispatcher_create(kx_model** models, int n_models, int max_bat
  * (free with kx_free_audio).  Equals kx_infer(B = 1, same seed, utterance base 0) bit for bit. */
 int kx_dispatcher_submit(kx_dispatcher* d, const int64_t* ids, int n_tokens, const float* style, float speed,
                          uint64_t seed, float** out, int64_t* out_len, char* err, size_t err_len);
+/* The request as the reference's servers make it (kokorox-openai/src/lib.rs:370-439, kokorox-websocket/src/lib.rs:
+ * 657-736): the voice is EITHER the 256-float style row (`style`, voice_ids = NULL) OR names into the device voice
+ * table every model of the dispatcher holds (kx_set_voice_table): `voice_ids[n_mix]` with `weights` = NULL and
+ * n_mix = 1 for a single voice (row copy), or with `weights[n_mix]` for a mix "a.4+b.5" (sum_k row_k * (w_k * 0.1),
+ * koko.rs:1255-1306; ids < 0 are skipped); `format` is a KX_PACK_* output form.  *out = malloc'd bytes
+ * (kx_free_audio); requests of every kind and format share batches, and a request's bytes equal those of
+ * kx_infer_voices / kx_infer_packed (B = 1, same seed, utterance base 0) whatever it was batched with.
+ * Errors are per request: when a batch fails as a whole its requests are re-run one by one. */
+int kx_dispatcher_submit_ex(kx_dispatcher* d, const int64_t* ids, int n_tokens, const float* style,
+                            const int32_t* voice_ids, const float* weights, int n_mix, float speed, uint64_t seed,
+                            int format, void** out, int64_t* out_bytes, int64_t* out_samples, char* err, size_t err_len);
 int kx_dispatcher_stats(kx_dispatcher* d, int64_t* n_requests, int64_t* n_batches, int64_t* max_batch_seen);
+/* batches each model (worker) has run so far: per_model[n_models] */
+int kx_dispatcher_model_batches(kx_dispatcher* d, int64_t* per_model, int n_models);
 void kx_dispatcher_destroy(kx_dispatcher* d);  /* waits for queued requests; models stay alive */
 
 /* ---- test hooks (used by tests/ only) --------------------------------------------- */
@@ -221,8 +242,8 @@ int kx_debug_tap(kx_model* m, const char* name, int b, float* out, int64_t out_c
 /* Stand-alone run of the conv1d MFMA kernel on host arrays (x [B,Cin,L], w [Cout,Cin,k]
  * or, for transposed = 1, [Cin,Cout,k]); y must hold B*Cout*Lout floats.  act: 0 none,
  * 1 leaky(slope), 2 snake(alpha[Cin]); norm = optional [3,B,Cin] (mean, scale, shift);
- * mode as in kx_set_conv_mode, plus 2 = f16x3 through the opt-in wave-specialised persistent kernel
- * (conv_f16x3_ws.hip; shapes it does not cover take the default f16x3 kernel). */
+ * mode as in kx_set_conv_mode, plus 2 = f16x3 on the LDS-DMA kernel forms only (conv_f16x3.hip: what the direct-A
+ * kernels are compared with bit for bit) and 3 = f16x3 through the direct-A kernel whatever the grid. */
 int kx_test_conv1d(int device_id, const float* x, int B, int Cin, int L, const float* w,
                    const float* bias, int Cout, int k, int stride, int pad, int dil,
                    int transposed, int act, float slope, const float* alpha,
@@ -251,6 +272,12 @@ int kx_test_attention(int device_id, const float* qkv, const int32_t* lens, int 
 int kx_test_source(int device_id, const float* f0, int B, int F2, const float* lin_w,
                    float lin_b, uint64_t seed, uint64_t utt_base, int noise_off, float* out,
                    char* err, size_t err_len);
+
+/* Fault injection for the two-CU LSTM recurrence (process-wide, test only): nth > 0 makes the nth following launch of
+ * the pair kernel, and every later one, lose the second half of each pair and poll with a short limit, so the call it
+ * belongs to must fail with KX_ERR_DEVICE (the bounded wait's error path) and the model must fall back to the one-CU
+ * kernel; 0 switches it off.  nth = 6 hits the frame-axis LSTM of a forward, after the mid-way error check. */
+int kx_test_lstm_fault(int nth);
 
 const char* kx_version(void);
 

@@ -62,6 +62,7 @@ extern "C" {
     fn kx_set_stft_variant(m: *mut KxModel, variant: c_int) -> c_int;
     fn kx_get_stft_variant(m: *mut KxModel) -> c_int;
     fn kx_set_utterance_base(m: *mut KxModel, utt_base: u64) -> c_int;
+    fn kx_set_lanes(m: *mut KxModel, n_lanes: c_int) -> c_int;
     fn kx_profile_enable(m: *mut KxModel, on: c_int) -> c_int;
     fn kx_profile_read(m: *mut KxModel, launches: *mut i64, total_ms: *mut f64, total_flops: *mut f64) -> c_int;
     fn kx_profile_detail(m: *mut KxModel, out: *mut f64, cap_rows: i64, n_rows: *mut i64) -> c_int;
@@ -84,8 +85,13 @@ extern "C" {
     fn kx_dispatcher_submit(d: *mut KxDispatcher, ids: *const i64, n_tokens: c_int, style: *const f32, speed: f32,
                             seed: u64, out: *mut *mut f32, out_len: *mut i64, err: *mut c_char,
                             err_len: usize) -> c_int;
+    fn kx_dispatcher_submit_ex(d: *mut KxDispatcher, ids: *const i64, n_tokens: c_int, style: *const f32,
+                               voice_ids: *const i32, weights: *const f32, n_mix: c_int, speed: f32, seed: u64,
+                               format: c_int, out: *mut *mut c_void, out_bytes: *mut i64, out_samples: *mut i64,
+                               err: *mut c_char, err_len: usize) -> c_int;
     fn kx_dispatcher_stats(d: *mut KxDispatcher, n_requests: *mut i64, n_batches: *mut i64,
                            max_batch_seen: *mut i64) -> c_int;
+    fn kx_dispatcher_model_batches(d: *mut KxDispatcher, per_model: *mut i64, n_models: c_int) -> c_int;
     fn kx_dispatcher_destroy(d: *mut KxDispatcher);
     fn kx_version() -> *const c_char;
 }
@@ -314,6 +320,10 @@ impl HipKoko {
     pub fn stft_variant(&self) -> i32 {
         unsafe { kx_get_stft_variant(self.h) }
     }
+    /// 1 = one stream; 4 = the independent chains of the back half on streams of their own; 0 (default) = by batch size.
+    pub fn set_lanes(&self, n: i32) -> Result<(), Box<dyn Error>> {
+        self.check(unsafe { kx_set_lanes(self.h, n) })
+    }
     pub fn set_utterance_base(&self, base: u64) -> Result<(), Box<dyn Error>> {
         self.check(unsafe { kx_set_utterance_base(self.h, base) })
     }
@@ -372,6 +382,13 @@ impl Drop for HipKoko {
 
 /// Batching front over one model per GPU: the replacement for the reference's one-request-at-a-time
 /// `Mutex<Session>` (ort_koko.rs:78; kokorox-openai/src/lib.rs:370-439, kokorox-websocket/src/lib.rs:657-668).
+/// How a dispatched request names its voice.
+pub enum Voice<'a> {
+    Row(&'a [f32]),
+    Single(i32),
+    Mix(&'a [(i32, f32)]),
+}
+
 /// `submit` blocks and may be called from any number of threads (tokio `spawn_blocking` in the servers).
 pub struct HipKokoDispatcher {
     d: *mut KxDispatcher,
@@ -412,6 +429,54 @@ impl HipKokoDispatcher {
         let v = unsafe { std::slice::from_raw_parts(out, n as usize) }.to_vec();
         unsafe { kx_free_audio(out) };
         Ok(v)
+    }
+
+    /// The request as the servers make it (kokorox-openai/src/lib.rs:370-439): the voice by name into the device voice
+    /// table -- `Voice::Single(id)` = row copy, `Voice::Mix(&[(id, weight)])` = "a.4+b.5" (koko.rs:1255-1306) -- or as
+    /// the 256-float row, and the output form (0 f32 mono, 1 f32 stereo, 2 PCM16).  Returns the packed bytes and the
+    /// sample count; bit-identical to the same request run alone.
+    pub fn submit_ex(&self, ids: &[i64], voice: Voice, speed: f32, seed: u64, format: i32)
+                     -> Result<(Vec<u8>, i64), Box<dyn Error>> {
+        let (mut vid, mut w): (Vec<i32>, Vec<f32>) = (Vec::new(), Vec::new());
+        let (style_p, vid_p, w_p, n_mix) = match voice {
+            Voice::Row(s) => {
+                if s.len() != KX_STYLE_DIM {
+                    return Err("submit_ex: the style row must have 256 floats".into());
+                }
+                (s.as_ptr(), ptr::null(), ptr::null(), 0)
+            }
+            Voice::Single(id) => {
+                vid.push(id);
+                (ptr::null(), vid.as_ptr(), ptr::null(), 1)
+            }
+            Voice::Mix(parts) => {
+                for (id, p) in parts {
+                    vid.push(*id);
+                    w.push(*p);
+                }
+                (ptr::null(), vid.as_ptr(), w.as_ptr(), vid.len() as c_int)
+            }
+        };
+        let mut out: *mut c_void = ptr::null_mut();
+        let (mut nb, mut ns) = (0i64, 0i64);
+        let mut err = vec![0 as c_char; 256];
+        let rc = unsafe {
+            kx_dispatcher_submit_ex(self.d, ids.as_ptr(), ids.len() as c_int, style_p, vid_p, w_p, n_mix, speed, seed,
+                                    format, &mut out, &mut nb, &mut ns, err.as_mut_ptr(), err.len())
+        };
+        if rc != KX_OK {
+            return Err(format!("kokorox_hip error {}: {}", rc, cstr_buf(&err)).into());
+        }
+        let v = unsafe { std::slice::from_raw_parts(out as *const u8, nb as usize) }.to_vec();
+        unsafe { kx_free_audio(out as *mut f32) };
+        Ok((v, ns))
+    }
+
+    /// Batches each model (GPU) has run so far.
+    pub fn model_batches(&self) -> Vec<i64> {
+        let mut v = vec![0i64; self._models.len()];
+        unsafe { kx_dispatcher_model_batches(self.d, v.as_mut_ptr(), v.len() as c_int) };
+        v
     }
 
     /// (requests, batches, largest batch) so far.

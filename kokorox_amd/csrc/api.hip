@@ -299,6 +299,19 @@ int kx_set_stft_variant(kx_model* m, int variant) {
 
 int kx_get_stft_variant(kx_model* m) { return (m && m->m) ? m->m->stft_variant : -1; }
 
+int kx_test_lstm_fault(int nth) {
+    kx::lstm_set_test_fault(nth);
+    return KX_OK;
+}
+
+int kx_set_lanes(kx_model* m, int n_lanes) {
+    return guarded(m, [&](Model& M) {
+        KX_REQUIRE(n_lanes >= 0 && n_lanes <= 4, "lanes must be 0 (by batch size) or 1..4");
+        M.sync();
+        M.set_lanes(n_lanes);
+    });
+}
+
 int kx_set_utterance_base(kx_model* m, uint64_t utt_base) {
     return guarded(m, [&](Model& M) { M.utt_base = utt_base; });
 }
@@ -403,7 +416,7 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
         std::vector<int> lens(B, 1);
         KX_REQUIRE(mode >= kx::CONV_F32 && mode <= kx::CONV_F16X3_DA, "test_conv1d: mode must be 0, 1, 2 or 3");
         kx::ConvArgs a{};
-        a.ws_force = mode == kx::CONV_F16X3_WS ? 1 : (mode == kx::CONV_F16X3_DA ? 2 : 0);
+        a.ws_force = mode == kx::CONV_F16X3_LDS ? 1 : (mode == kx::CONV_F16X3_DA ? 2 : 0);
         a.x = dm.up(x, (size_t)B * Cin * L);
         a.x_bs = (long)Cin * L;
         a.x_ld = L;

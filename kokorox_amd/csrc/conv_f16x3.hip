@@ -448,10 +448,6 @@ static void launch_inst16(const ConvArgs& a, int B, int max_cols, hipStream_t s)
 //   the 256-wide tile and results stay bit-identical across batch sizes.
 void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int stride, int* bn, int* wn, int ws_force) {
     static const int force = env_int("KX_BN", 0);
-    if (conv16_use_ws(BM, K, dil, stride, 0) || (ws_force == 1 && conv16_ws_eligible(BM, K, dil, stride, 0))) {
-        conv16_ws_tile(max_cols, B, Cout, bn, wn);
-        return;
-    }
     if (ws_force == 2 && conv16_da_eligible(BM, K, dil, stride, 0)) {  // test hook: the direct-A kernel whatever the grid
         *bn = 256; *wn = 2;
         return;
@@ -475,11 +471,6 @@ void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStre
     KX_REQUIRE(a.n_chunks16 == (a.Cin + CK16 - 1) / CK16 && a.w16 != nullptr, "conv1d f16x3: weights not packed");
     KX_REQUIRE(BM == 128 || a.epi != EPI_GELU_NEW, "conv1d f16x3: gelu epilogue needs the 128-row tile");
     if (max_cols <= 0) return;
-    if (conv16_use_ws(BM, a.K, a.dil, a.stride, a.merge_T > 0) ||
-        (a.ws_force == 1 && conv16_ws_eligible(BM, a.K, a.dil, a.stride, a.merge_T > 0))) {
-        launch_conv1d_f16x3_ws(a, B, max_cols, s);
-        return;
-    }
     if (BM == 128) {
         // (an 8-wave x 128-register form of the 128x256 tile was tried: it spills and is 6 % slower)
         // (also tried: a 128x192 tile for 3 workgroups per CU: the 168-register cap spills in the main loop, 1.7x slower)
@@ -520,7 +511,7 @@ void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStre
             launch_inst16<128, 128, 4, 1>(a, B, max_cols, s);
         else if (bn == 128)
             launch_inst16<128, 128, 2, 2>(a, B, max_cols, s);
-        else if (conv16_use_da(BM, a.K, a.dil, a.stride, a.merge_T > 0))
+        else if (conv16_use_da(BM, a.K, a.dil, a.stride, a.merge_T > 0) && a.ws_force != 1)
             launch_conv1d_f16x3_da(a, B, max_cols, s);
         else
             launch_inst16<128, 256, 2, 2>(a, B, max_cols, s);

@@ -1,4 +1,4 @@
-// Device helpers shared by the two f16x3 conv kernels (conv_f16x3.hip, conv_f16x3_ws.hip): the split-f16 operand
+// Device helpers shared by the f16x3 conv kernels (conv_f16x3.hip, conv_f16x3_da.hip, conv_f16x3_dag.hip): the split-f16 operand
 // format, the snake / leaky input activation and the asynchronous global -> LDS copy.
 #pragma once
 #include "conv_epilogue.h"

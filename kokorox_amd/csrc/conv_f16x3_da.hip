@@ -5,7 +5,7 @@
 // (global_load_lds), 24 one-KiB copy instructions per 3-tap piece and workgroup.  Removing those copies (KX_DBG bit 2)
 // takes the 128 -> 128, k = 11 launches from 25.7 to 18.0 ms per step; keeping every copy INSTRUCTION but pointing them
 // all at one hot KiB (bit 256) leaves 24.8 ms: the cost is the copy instructions, not their bytes.  A CU moves
-// ~12 B/clk through LDS-DMA while the fragment reads keep the LDS busy (the wave-specialised kernel's producers measured
+// ~12 B/clk through LDS-DMA while the fragment reads keep the LDS busy (the producers of a wave-specialised form that was built and dropped in round 2 measured
 // ~350 cycles of issue per copy), two workgroups per CU need 24 GB/s of weights, and every copy a wave issues is time it
 // cannot issue MFMAs; with the weight stream gone, input staging and epilogue cost 1.1 ms each instead of 6.6 / 6.9.
 //
@@ -92,6 +92,18 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         if (a.xcd_swizzle) {
             tile_x = lp / ny;
             ct = lp - tile_x * ny;
+        }
+    }
+    // De-phasing (a.dephase_cycles > 0): workgroups of one launch all take the same time per tile, so the workgroups that
+    // start together reach their epilogues together and the chip alternates between a phase with the matrix pipes busy
+    // and HBM idle and one with every CU storing at once.  A chosen half of the FIRST round of workgroups starts half a
+    // tile late (once per launch); the offset then persists from tile to tile.
+    if (a.dephase_cycles > 0) {
+        const unsigned gl = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);  // dispatch order
+        const bool late = a.dephase_mode == 1 ? (gl < 512u && ((gl >> 3) & 1u)) : (gl >= 256u && gl < 512u);
+        if (late) {
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime() + (unsigned long long)a.dephase_cycles;
+            while (__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(64);
         }
     }
     const int t0 = tile_x * BN;
@@ -570,6 +582,18 @@ void launch_conv1d_f16x3_da(const ConvArgs& a, int B, int max_cols, hipStream_t 
     KX_REQUIRE(a.epi != EPI_GELU_NEW, "conv1d f16x3 da: no gelu epilogue");
     KX_REQUIRE(bn == 256 || bn == 128, "conv1d f16x3 da: tile of 256 or 128 columns");
     if (max_cols <= 0) return;
+    static const int dephase = getenv("KX_DEPHASE") ? atoi(getenv("KX_DEPHASE")) : 0;  // permille of a tile's estimated time
+    static const int dephase_mode = getenv("KX_DEPHASE_MODE") ? atoi(getenv("KX_DEPHASE_MODE")) : 1;
+    if (dephase > 0 && bn == 256) {
+        ConvArgs d = a;
+        const long grid_n = (long)((max_cols + 255) / 256) * ((a.Cout + 127) / 128) * B;
+        // a tile: n_chunks x K x 8 column tiles x 3 MFMAs of 32 cycles, two waves per SIMD, ~80 % pipe use; + the epilogue
+        const double tile_cycles = (double)a.n_chunks16 * a.K * 8 * 96 * 2.5 + 50000.0;
+        d.dephase_cycles = grid_n >= 1024 ? (int)(tile_cycles * dephase / 1000.0) : 0;
+        d.dephase_mode = dephase_mode;
+        launch_da_ntt<8>(d, B, max_cols, s);
+        return;
+    }
     if (bn == 256)
         launch_da_ntt<8>(a, B, max_cols, s);
     else

@@ -391,15 +391,19 @@ void launch_stats_finalize(const float2* part, int tiles, int cols_per_tile, int
 // TTSKoko::mix_styles (kokorox/src/tts/koko.rs:1255-1306): single voice = copy of row `tokens_len`;
 // "a.4+b.5" = sum_k row_k * (w_k * 0.1) accumulated in order, f32, no normalisation (0.4 + 0.5 = 0.9 is used
 // as is).  Multiplies and adds are kept un-fused so the result equals the host mixer bit for bit.
+// kinds (optional, per utterance): 0 = the style row was given explicitly (nothing to do), 1 = single voice (copy),
+// 2 = mix; null = the whole batch is single (max_mix == 1) or mixes.
 __global__ void style_mix_kernel(const float* table, int n_voices, const int* voice_ids, const float* weights,
-                                 int max_mix, const int* rows, float* styles) {
+                                 int max_mix, const int* rows, const int* kinds, float* styles) {
 #pragma clang fp contract(off)  // (HIP's __fmul_rn / __fadd_rn are plain * and +: without this they fuse into an FMA)
     const int b = blockIdx.x, j = threadIdx.x;
+    const int kind = kinds ? kinds[b] : (max_mix == 1 ? 1 : 2);
+    if (kind == 0) return;
     const int row = rows[b];
     const int* v = voice_ids + (long)b * max_mix;
     const float* w = weights + (long)b * max_mix;
     float acc = 0.f;
-    if (max_mix == 1) {
+    if (kind == 1) {
         acc = table[((long)v[0] * 511 + row) * 256 + j];
     } else {
         for (int k = 0; k < max_mix; ++k) {
@@ -412,20 +416,21 @@ __global__ void style_mix_kernel(const float* table, int n_voices, const int* vo
     styles[(long)b * 256 + j] = acc;
 }
 void launch_style_mix(const float* table, int n_voices, const int* voice_ids, const float* weights, int max_mix,
-                      const int* rows, float* styles, int B, hipStream_t s) {
+                      const int* rows, const int* kinds, float* styles, int B, hipStream_t s) {
     hipLaunchKernelGGL(style_mix_kernel, dim3(B), dim3(256), 0, s, table, n_voices, voice_ids, weights, max_mix, rows,
-                       styles);
+                       kinds, styles);
     KX_HIP(hipGetLastError());
 }
 
 // ---- output packing on device ------------------------------------------------------------------------
 // f32 stereo = every sample written twice (koko.rs:1239-1246); PCM16 = (s.clamp(-1,1) * 32767) as i16,
 // i.e. truncation toward zero, NaN -> 0 (kokorox-websocket/src/lib.rs:701-704).
-__global__ void pack_audio_kernel(const float* audio, long audio_ld, const int* frames, int format, void* out,
-                                  long out_stride_bytes, const long* out_off) {
+__global__ void pack_audio_kernel(const float* audio, long audio_ld, const int* frames, int format, const int* formats,
+                                  void* out, long out_stride_bytes, const long* out_off) {
     const long j = blockIdx.x * (long)blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (j >= 600L * frames[b]) return;
+    if (formats) format = formats[b];  // (per utterance: requests of one dispatched batch may differ)
     const float sv = audio[b * audio_ld + j];
     // out_off: byte offset of utterance b in a compact output (utterances back to back); else a fixed stride
     char* ob = static_cast<char*>(out) + (out_off ? out_off[b] : b * out_stride_bytes);
@@ -439,9 +444,9 @@ __global__ void pack_audio_kernel(const float* audio, long audio_ld, const int* 
     }
 }
 void launch_pack_audio(const float* audio, long audio_ld, const int* frames, int B, int Fmax, int format, void* out,
-                       long out_stride_bytes, const long* out_off, hipStream_t s) {
+                       long out_stride_bytes, const long* out_off, hipStream_t s, const int* formats) {
     hipLaunchKernelGGL(pack_audio_kernel, dim3((600 * Fmax + 255) / 256, B), dim3(256), 0, s, audio, audio_ld, frames,
-                       format, out, out_stride_bytes, out_off);
+                       format, formats, out, out_stride_bytes, out_off);
     KX_HIP(hipGetLastError());
 }
 
@@ -600,7 +605,7 @@ constexpr int LSTMP_LDS = 32 - LSTMP_REG;
 __global__ __launch_bounds__(1024) void lstm_pair_kernel(const float* gx, long gx_bs, int gx_ld, const float* whhT,
                                                          float* y, long y_bs, int y_ld, LenMap len,
                                                          unsigned long long* xchg, unsigned epoch, unsigned* err,
-                                                         int n_pairs) {
+                                                         int n_pairs, int spin_limit, int drop_half) {
     extern __shared__ __attribute__((aligned(16))) float lstm_smem[];
     float* hs = lstm_smem;                                   // [256] h of the previous step (both halves)
     float* gates = hs + 256;                                 // [512] gate pre-activations of this half
@@ -610,6 +615,7 @@ __global__ __launch_bounds__(1024) void lstm_pair_kernel(const float* gx, long g
     // both halves share one XCD's L2 and the hand-off does not cross the fabric (speed only: nothing depends on it).
     const int hf = (blockIdx.x >> 3) & 1, pair = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);  // pair = b * 2 + dir
     if (pair >= n_pairs) return;                             // (padding blocks of the last group)
+    if (drop_half && hf == 1) return;                        // (test hook: the partner that never shows up)
     const int b = pair >> 1, dir = pair & 1, tid = threadIdx.x;
     const int L = len_of(len, b);
     // a wave owns 32 rows; its lower half-wave walks k 0..127 of them, the upper one k 128..255 (combined with one
@@ -683,7 +689,7 @@ __global__ __launch_bounds__(1024) void lstm_pair_kernel(const float* gx, long g
             for (;;) {
                 g8 = __hip_atomic_load(theirs + par * 256 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)(g8 >> 32) == tag) break;
-                if (++spins > (1 << 22)) {  // ~ seconds: the partner is not coming
+                if (++spins > spin_limit) {  // (1 << 22 ~ seconds: the partner is not coming)
                     atomicOr(err, 2u);
                     *abort_flag = 1;
                     g8 = 0;
@@ -698,6 +704,12 @@ __global__ __launch_bounds__(1024) void lstm_pair_kernel(const float* gx, long g
     }
 }
 
+// test hook (kx_test_lstm_fault): n > 0 = from the n-th launch of the two-CU kernel on, every launch loses the second half
+// of each pair and polls with a short limit, so that the bounded wait's error path can be exercised (n = 6: the
+// frame-axis LSTM of a forward, which runs after the forward's mid-way error check)
+static std::atomic<int> lstm_test_fault{0};
+void lstm_set_test_fault(int nth) { lstm_test_fault.store(nth > 0 ? nth : 0); }
+
 static bool lstm_use_pair() {
     static const int v = getenv("KX_LSTM_PAIR") ? atoi(getenv("KX_LSTM_PAIR")) : 1;
     return v != 0;
@@ -706,7 +718,7 @@ static bool lstm_use_pair() {
 size_t lstm_exchange_bytes(int B) { return (size_t)B * 2 * 2 * 2 * 128 * sizeof(unsigned long long); }
 
 void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, float* y, long y_bs, int y_ld,
-                 LenMap len, int B, unsigned long long* xchg, unsigned* err_word, hipStream_t s) {
+                 LenMap len, int B, unsigned long long* xchg, unsigned* err_word, hipStream_t s, unsigned* epoch_state) {
     static_assert(LSTM_LDS_K % 4 == 0 && LSTM_REG_K % 4 == 0, "whole float4 groups of h");
     if (lstm_use_pair() && xchg && err_word) {
         const size_t lds = sizeof(float) * (256 + 512 + 4 + (size_t)LSTMP_LDS * 1024 * 4);
@@ -716,12 +728,29 @@ void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, floa
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             pair_attr = true;
         }
-        static std::atomic<unsigned> epoch_ctr{0};
-        unsigned epoch = (epoch_ctr.fetch_add(1) + 1) & 0xffffu;
-        if (epoch == 0) epoch = (epoch_ctr.fetch_add(1) + 1) & 0xffffu;  // (0 is what a fresh buffer holds)
+        // The tag's epoch is 16 bits wide and counted PER exchange buffer (epoch_state; the test hook's one-shot buffer has
+        // none): when it wraps the buffer is cleared in stream order, so a granule of 65535 launches ago can never carry
+        // the tag of a live step.  (0 is what a cleared buffer holds and is never used as an epoch.)
+        static std::atomic<unsigned> hook_ctr{0};
+        unsigned epoch;
+        if (epoch_state) {
+            epoch = (*epoch_state + 1) & 0xffffu;
+            if (epoch == 0) {
+                KX_HIP(hipMemsetAsync(xchg, 0, lstm_exchange_bytes(B), s));
+                epoch = 1;
+            }
+            *epoch_state = epoch;
+        } else {
+            epoch = (hook_ctr.fetch_add(1) % 0xffffu) + 1;
+        }
         const int n_pairs = B * 2;  // (utterance, direction); blocks come in groups of 16 = 8 pairs
+        int fault = lstm_test_fault.load();
+        if (fault > 1) {  // (count down to the launch that fails)
+            lstm_test_fault.store(fault - 1);
+            fault = 0;
+        }
         hipLaunchKernelGGL(lstm_pair_kernel, dim3(((n_pairs + 7) / 8) * 16), dim3(1024), lds, s, gx, gx_bs, gx_ld, whhT, y, y_bs,
-                           y_ld, len, xchg, epoch, err_word, n_pairs);
+                           y_ld, len, xchg, epoch, err_word, n_pairs, fault ? (1 << 10) : (1 << 22), fault);
         KX_HIP(hipGetLastError());
         return;
     }

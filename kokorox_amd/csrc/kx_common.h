@@ -91,9 +91,9 @@ struct ConvArgs {
     float2* stat_part;  // optional [B][Cout][stat_tiles] partial (sum, sum of squares) of the stored values
     int stat_tiles;
     int xcd_swizzle;               // one-role f16x3 kernel: contiguous column tiles per XCD (1 unless KX_XCD_SWIZZLE=0)
-    int ws_force;                  // test hook: 1 = take the wave-specialised kernel when the shape is eligible, 2 = the direct-A kernel
-    int ws_ntx, ws_nty, ws_tiles;  // persistent wave-specialised kernel: column tiles, row tiles, all tiles (set by its launcher)
+    int ws_force;                  // test hook: 1 = the LDS-DMA kernel forms only (no direct-A kernel), 2 = the direct-A kernel whatever the grid
     unsigned long long* stamps;  // diagnostic build only: per-workgroup {t0,t1,t2,t3,hw_id,xcc_id,0,0}
+    int dephase_cycles, dephase_mode;  // direct-A conv: start delay of half of the first round of workgroups (0 = off)
     int dbg;  // timing ablations (env KX_DBG): 1 skip input staging, 2 skip weight copies, 4 skip MFMA, 8 skip epilogue
 };
 
@@ -116,15 +116,10 @@ void launch_pack_convT(const float* w, float* dst, int Cin, int Cout, int s, int
 size_t packed_conv_floats(int rows, int Cin, int K, int BM);
 
 // f16x3 split path
-enum ConvMode { CONV_F32 = 0, CONV_F16X3 = 1, CONV_F16X3_WS = 2, CONV_F16X3_DA = 3 };  // (2, 3: test hook only: f16x3 forced through conv_f16x3_ws.hip / conv_f16x3_da.hip)
+enum ConvMode { CONV_F32 = 0, CONV_F16X3 = 1, CONV_F16X3_LDS = 2, CONV_F16X3_DA = 3 };  // (2, 3: test hook only: f16x3 kept on the LDS-DMA kernel forms of conv_f16x3.hip / forced through conv_f16x3_da.hip)
 void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStream_t s);
 void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int stride, int* bn, int* wn,
                       int ws_force = 0);  // (conv_f16x3.hip)
-// wave-specialised form (conv_f16x3_ws.hip): which launches take it, its tile, its launcher
-bool conv16_use_ws(int BM, int K, int dil, int stride, int merged);       // eligible AND switched on (KX_WS=1)
-bool conv16_ws_eligible(int BM, int K, int dil, int stride, int merged);  // shape fits the kernel
-void conv16_ws_tile(int max_cols, int B, int Cout, int* bn, int* wn);
-void launch_conv1d_f16x3_ws(const ConvArgs& a, int B, int max_cols, hipStream_t s);
 // conv_f16x3_da.hip: the 128 x 256 tile with the weight fragments loaded from global memory straight into registers
 bool conv16_use_da(int BM, int K, int dil, int stride, int merged);       // eligible AND switched on (default; KX_DA=0 turns it off)
 bool conv16_da_eligible(int BM, int K, int dil, int stride, int merged);  // shape fits the kernel
@@ -181,9 +176,9 @@ void launch_diag_stats(const float* x, long bs, int ld, int C, LenMap len, int B
                        const float* nscale, const float* nshift, int n_bs, float* out3, hipStream_t s);
 
 void launch_style_mix(const float* table, int n_voices, const int* voice_ids, const float* weights, int max_mix,
-                      const int* rows, float* styles, int B, hipStream_t s);
+                      const int* rows, const int* kinds, float* styles, int B, hipStream_t s);
 void launch_pack_audio(const float* audio, long audio_ld, const int* frames, int B, int Fmax, int format, void* out,
-                       long out_stride_bytes, const long* out_off, hipStream_t s);
+                       long out_stride_bytes, const long* out_off, hipStream_t s, const int* formats = nullptr);
 // Host output buffers of the kx_infer* calls: page-locked and pooled (one asynchronous D2H copy at PCIe rate instead
 // of per-utterance pageable copies); host_out_free also accepts plain malloc'd pointers (dispatcher results).
 void* host_out_alloc(size_t bytes);
@@ -196,8 +191,10 @@ void launch_copy_rows(const float* src, long sbs, int sld, float* dst, long dbs,
 // xchg / err_word: exchange buffer (lstm_exchange_bytes(B), any contents) and sticky error word of the two-CU form;
 // null = the one-CU streaming kernel
 void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, float* y, long y_bs, int y_ld,
-                 LenMap len, int B, unsigned long long* xchg, unsigned* err_word, hipStream_t s);
+                 LenMap len, int B, unsigned long long* xchg, unsigned* err_word, hipStream_t s,
+                 unsigned* epoch_state = nullptr);  // epoch_state: the buffer's own launch counter (see launch_lstm)
 size_t lstm_exchange_bytes(int B);
+void lstm_set_test_fault(int on);  // test hook: the two-CU kernel's partner never shows up (bounded-poll error path)
 
 void launch_duration(const float* logits, long bs, int ld, const float* speeds, int n_speed, const int* lens,
                      const int* pinned, int n_pinned, int* dur, int* frames, int* idx, int idx_ld, int B,

@@ -114,6 +114,9 @@ class Model {
         int max_mix = 0;
         const uint64_t* utt_seeds = nullptr;
         int format = 0;                      // 0 f32 mono, 1 f32 stereo, 2 pcm16 mono
+        // per-utterance forms (the dispatcher's mixed batches); null = the batch-wide fields above
+        const int32_t* kinds = nullptr;      // host [B]: 0 = row of `styles`, 1 = single voice (copy), 2 = mix
+        const int32_t* formats = nullptr;    // host [B]
     };
     void infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* lens, int B, const float* speeds,
                        int n_speed, uint64_t seed, uint32_t flags, const HostCall& hc, void** out, int64_t* out_bytes,
@@ -137,6 +140,7 @@ class Model {
     std::mutex mu;
     std::string last_error;
     uint64_t utt_base = 0;
+    void set_lanes(int n) { lanes_cfg_ = n < 0 ? 0 : (n > N_LANES ? N_LANES : n); }
     int conv_mode = CONV_F16X3;
     int stft_variant = STFT_ONNX;  // the ONNX export's conv-based STFT pair (what the reference runs)
     int device;
@@ -160,10 +164,29 @@ class Model {
     void adain_resblk(const std::string& name, const T& x, const T& out, bool upsample, float* ws_a, float* ws_b,
                       float* ws_c);
     void adain_resblock1(const std::string& name, int k, const T& x, const T& xj, const T& t1, const T& out,
-                         int accum, float out_div, float2* part_t1, float2* part_xj);
+                         int accum, float out_div, float2* part_t1, float2* part_xj, hipEvent_t wait_before_last = nullptr);
     void lstm(const LstmW& w, const T& in, const T& out, float* gx);
     void tap(const char* name, const T& t);
     void ensure_arena(Arena& a, size_t bytes);
+
+    // Lanes of the back half: chains that do not depend on each other (the harmonic-source / noise path, the three
+    // resblocks of a generator stage) are issued on streams of their own and meet through events, so that the HBM-bound
+    // phases of one chain (epilogues, statistics passes, k = 3 convs) run under the matrix work of another.  Lane 0 is the
+    // main stream.  Every lane has its own InstanceNorm parameter set (stats() writes it, the next conv reads it).
+    static constexpr int N_LANES = 4;
+    struct Lane {
+        hipStream_t stream = nullptr;
+        float *nmean = nullptr, *nscale = nullptr, *nshift = nullptr;
+    };
+    Lane lanes_[N_LANES];
+    int lanes_cfg_ = 0;  // 0 = by batch size (4 up to 16 utterances, else 1), 1..4 = fixed (KX_LANES, kx_set_lanes)
+    int n_lanes_ = 1;    // lanes of the running call
+    std::vector<hipEvent_t> lane_ev_;
+    size_t lane_ev_used_ = 0;
+    hipEvent_t record_here();               // a pooled event recorded on the current stream (null in the sizing pass)
+    void wait_here(hipEvent_t e);           // the current stream waits for it
+    struct LaneScope;                       // issue on lane k until the scope ends (model.hip)
+    void sync_lanes();
 
     hipStream_t stream_ = nullptr;
     // side stream for the TextEncoder branch, which does not depend on the ALBERT / duration branch
@@ -197,6 +220,10 @@ class Model {
     // sticky device error word (bit 1: a half never saw its partner) checked at every host synchronisation
     unsigned long long* d_xchg_[2] = {nullptr, nullptr};
     size_t xchg_cap_ = 0;
+    unsigned xchg_epoch_[2] = {0, 0};  // launches on each exchange buffer since it was last cleared (16-bit tag epoch)
+    bool lstm_pair_ok_ = true;         // false once a hand-off timed out: the one-CU kernel from then on
+    std::vector<long> h_off_;          // host staging that asynchronous copies read / write: outlives the calling frame
+    unsigned h_bad_id_ = 0;
     unsigned* d_dev_err_ = nullptr;
     hipStream_t main_stream_ = nullptr;
     void check_dev_err();

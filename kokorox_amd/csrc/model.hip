@@ -22,6 +22,9 @@ Model::Model(int dev) : device(dev) {
     KX_HIP(hipMalloc((void**)&d_dev_err_, sizeof(unsigned)));
     KX_HIP(hipMemset(d_dev_err_, 0, sizeof(unsigned)));
     KX_HIP(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+    lanes_[0].stream = stream_;
+    for (int i = 1; i < N_LANES; ++i) KX_HIP(hipStreamCreateWithFlags(&lanes_[i].stream, hipStreamNonBlocking));
+    if (const char* e = getenv("KX_LANES")) set_lanes(atoi(e));
     KX_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     KX_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     init_dft_tables();
@@ -31,6 +34,12 @@ Model::~Model() {
     (void)hipSetDevice(device);
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (stream2_) (void)hipStreamSynchronize(stream2_);
+    for (int i = 1; i < N_LANES; ++i)
+        if (lanes_[i].stream) {
+            (void)hipStreamSynchronize(lanes_[i].stream);
+            (void)hipStreamDestroy(lanes_[i].stream);
+        }
+    for (hipEvent_t e : lane_ev_) (void)hipEventDestroy(e);
     for (void* p : owned_) (void)hipFree(p);
     if (d_dev_err_) (void)hipFree(d_dev_err_);
     for (auto* p : d_xchg_)
@@ -377,6 +386,53 @@ void Model::ensure_arena(Arena& a, size_t bytes) {
 
 
 
+// ---- lanes (model.h) ---------------------------------------------------------------------------
+hipEvent_t Model::record_here() {
+    if (dry_) return nullptr;
+    if (lane_ev_used_ == lane_ev_.size()) {
+        hipEvent_t e;
+        KX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        lane_ev_.push_back(e);
+    }
+    hipEvent_t e = lane_ev_[lane_ev_used_++];
+    KX_HIP(hipEventRecord(e, stream_));
+    return e;
+}
+
+void Model::wait_here(hipEvent_t e) {
+    if (dry_ || !e) return;
+    KX_HIP(hipStreamWaitEvent(stream_, e, 0));
+}
+
+void Model::sync_lanes() {
+    for (int i = 1; i < N_LANES; ++i)
+        if (lanes_[i].stream) (void)hipStreamSynchronize(lanes_[i].stream);
+}
+
+// Everything issued inside the scope goes to lane k (its stream, its InstanceNorm parameter set), which first waits for
+// what the issuing stream has queued so far.  Leaving the scope joins nothing: chains meet through record_here / wait_here.
+struct Model::LaneScope {
+    Model& m;
+    hipStream_t s0;
+    float *a0, *b0, *c0;
+    LaneScope(Model& mm, int k) : m(mm), s0(mm.stream_), a0(mm.nmean_), b0(mm.nscale_), c0(mm.nshift_) {
+        const Lane& L = m.lanes_[k < m.n_lanes_ ? k : 0];
+        if (L.stream == m.stream_) return;
+        hipEvent_t e = m.record_here();
+        m.stream_ = L.stream;
+        m.nmean_ = L.nmean;
+        m.nscale_ = L.nscale;
+        m.nshift_ = L.nshift;
+        m.wait_here(e);
+    }
+    ~LaneScope() {
+        m.stream_ = s0;
+        m.nmean_ = a0;
+        m.nscale_ = b0;
+        m.nshift_ = c0;
+    }
+};
+
 void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     if (dry_) return;
     ConvArgs a{};
@@ -479,7 +535,7 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
         KX_HIP(hipMemsetAsync(d_stamps, 0, n_wg * 64, stream_));
         a.stamps = d_stamps;
     }
-    if (prof_on_ && w.BM == 128) {  // the dominant instantiation conv1d_mfma_kernel<128,128,2,2>
+    if (prof_on_ && w.BM == 128) {  // the dominant kernel family: every 128-row conv / GEMM launch (direct-A, direct-A GEMM, LDS-DMA forms; f32 mode: conv1d_mfma_kernel<128,128,2,2>)
         const LenMap& lm = (o.store == ST_UPSCATTER) ? in.len : out.len;
         const std::vector<int>& hl = (lm.lens == dT_) ? hT_ : hF_;
         double cols = 0;
@@ -586,8 +642,10 @@ void Model::lstm(const LstmW& w, const T& in, const T& out, float* gx) {
     ConvOpts o;
     o.store = ST_TMAJOR;
     conv(w.ih, in, g, o);
-    launch_lstm(gx, g.bs, 2048, w.whhT, out.p, out.bs, out.ld, in.len, B_, d_xchg_[stream_ == main_stream_ ? 0 : 1],
-                d_dev_err_, stream_);
+    // (after a timed-out hand-off the model stays on the one-CU kernel: see check_dev_err)
+    const int xb = stream_ == main_stream_ ? 0 : 1;
+    launch_lstm(gx, g.bs, 2048, w.whhT, out.p, out.bs, out.ld, in.len, B_, lstm_pair_ok_ ? d_xchg_[xb] : nullptr,
+                d_dev_err_, stream_, &xchg_epoch_[xb]);
 }
 
 // AdainResBlk1d (istftnet.py): out = (conv2(act(norm2(conv1(pool(act(norm1(x))))))) + shortcut(x)) / sqrt(2)
@@ -640,7 +698,7 @@ void Model::adain_resblk(const std::string& name, const T& x, const T& out, bool
 // AdaINResBlock1 with Snake1D (istftnet.py).  x is read-only; xj/t1 are scratch of x's shape;
 // the third iteration lands in `out` (optionally accumulated and divided: mean over kernels).
 void Model::adain_resblock1(const std::string& name, int k, const T& x, const T& xj, const T& t1, const T& out,
-                            int accum, float out_div, float2* part_t1, float2* part_xj) {
+                            int accum, float out_div, float2* part_t1, float2* part_xj, hipEvent_t wait_before_last) {
     static const int dils[3] = {1, 3, 5};
     for (int i = 0; i < 3; ++i) {
         const std::string s = std::to_string(i);
@@ -665,6 +723,7 @@ void Model::adain_resblock1(const std::string& name, int k, const T& x, const T&
         if (i == 2) {
             o2.accum = accum;
             o2.out_div = out_div;
+            wait_here(wait_before_last);  // (the running sum this conv adds to is written by another lane)
         } else {
             o2.stat_part = part_xj;  // xj is normalised by the next iteration's adain1
         }
@@ -684,8 +743,10 @@ void Model::check_dev_err() {
     KX_HIP(hipMemcpy(&e, d_dev_err_, sizeof(unsigned), hipMemcpyDeviceToHost));
     if (!e) return;
     KX_HIP(hipMemset(d_dev_err_, 0, sizeof(unsigned)));
+    lstm_pair_ok_ = false;
     throw Error(3, "device error word " + std::to_string(e) +
-                       ": a half of the two-CU LSTM recurrence never saw its partner (set KX_LSTM_PAIR=0 for the one-CU kernel)");
+                       ": a half of the two-CU LSTM recurrence never saw its partner; this call failed, the model uses the "
+                       "one-CU kernel from now on (KX_LSTM_PAIR=0 selects it from the start)");
 }
 
 void Model::set_pinned(const int32_t* pattern, int n) {
@@ -811,6 +872,11 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     taps_on_ = (flags & 2u) != 0;
     taps_.clear();
     parts_.clear();
+    lane_ev_used_ = 0;
+    // Measured (profiles/r03_lanes_dephase.txt): at batch 1 the side-by-side chains take 10 % off the step (small grids
+    // leave CUs idle: 13.8 -> 12.3 ms); at batch 64 every launch fills the chip and they change nothing (125.1 vs 125.1 ms)
+    // while the per-launch event timings of the profile mode would overlap.  So: lanes for small batches only.
+    n_lanes_ = lanes_cfg_ ? lanes_cfg_ : (B <= 16 ? N_LANES : 1);
     hT_.assign(lens_host, lens_host + B);
     hF_.assign(B, 0);
     const int Tp = up4(Tmax);
@@ -826,6 +892,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
             KX_HIP(hipMemset(p, 0, lstm_exchange_bytes(B)));
         }
         xchg_cap_ = lstm_exchange_bytes(B);
+        xchg_epoch_[0] = xchg_epoch_[1] = 0;
     }
 
     // ===== front half: everything on the token axis ==========================================
@@ -843,6 +910,14 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
         nmean_ = A.f((size_t)B * n_bs_);
         nscale_ = A.f((size_t)B * n_bs_);
         nshift_ = A.f((size_t)B * n_bs_);
+        lanes_[0].nmean = nmean_;
+        lanes_[0].nscale = nscale_;
+        lanes_[0].nshift = nshift_;
+        for (int i = 1; i < N_LANES; ++i) {
+            lanes_[i].nmean = A.f((size_t)B * n_bs_);
+            lanes_[i].nscale = A.f((size_t)B * n_bs_);
+            lanes_[i].nshift = A.f((size_t)B * n_bs_);
+        }
         const size_t bt = (size_t)B * Tp;
         emb = A.f(bt * 128);
         h = A.f(bt * 768);
@@ -962,15 +1037,15 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     launch_duration(logits, t_logits.bs, Tp, d_speeds, n_speed, dT_, d_pinned_, n_pinned_, dur, dF_, idx, idx_ld, B,
                     stream_);
     KX_HIP(hipMemcpyAsync(hF_.data(), dF_, B * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    unsigned bad_id = 0;
-    KX_HIP(hipMemcpyAsync(&bad_id, d_bad_id_, sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
+    h_bad_id_ = 0;
+    KX_HIP(hipMemcpyAsync(&h_bad_id_, d_bad_id_, sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
 
     // ===== the one host round trip: predicted frame counts size everything downstream =========
     KX_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));  // the TextEncoder branch joins here
     KX_HIP(hipStreamSynchronize(stream_));
     check_dev_err();
-    if (bad_id) {  // a device-side id outside the embedding tables (clamped for the gather, never read out of bounds)
-        const unsigned w = bad_id - 1;
+    if (h_bad_id_) {  // a device-side id outside the embedding tables (clamped for the gather, never read out of bounds)
+        const unsigned w = h_bad_id_ - 1;
         throw Error(1, "infer: token id outside 0.." + std::to_string(n_vocab_ - 1) + " (utterance " + std::to_string(w >> 16) +
                            ", position " + std::to_string(w & 0xffffu) + ")");
     }
@@ -1021,6 +1096,48 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
         }
         tap("pred.F0", curves.rows(0, 1));
         tap("pred.N", curves.rows(1, 1));
+        // --- Generator, source side: harmonic source -> STFT -> noise_convs / noise_res of both stages.  It depends on the
+        // F0 curve only, so it runs on a lane of its own beside the decoder and the first generator stage.
+        const std::string G = "decoder.generator.";
+        T ns[2];
+        hipEvent_t ev_ns[2] = {nullptr, nullptr};
+        size_t part_n[2];
+        {
+            LaneScope on_lane(*this, 3);
+            const long hs_ld = (long)600 * Fmax;
+            float* har_src = A.f((size_t)B * hs_ld);
+            float* phase = A.f((size_t)B * 9 * 2 * Fmax);
+            if (!dry_)
+                launch_source(curves.p, curves.bs, dF_, B, Fmax, wt(G + "m_source.l_linear.weight"),
+                              wt(G + "m_source.l_linear.bias"), seed, utt_base, d_utt_seeds_, noise_off, phase, har_src, hs_ld, stream_);
+            if (taps_on_ && !dry_) {
+                T hs;
+                hs.p = har_src; hs.bs = hs_ld; hs.ld = (int)hs_ld; hs.C = 1; hs.len = LenMap{dF_, 600, 0}; hs.Lmax = 600 * Fmax;
+                tap("gen.har_source", hs);
+            }
+            T har = F121(22);
+            if (!dry_) launch_stft(har_src, hs_ld, har.p, har.bs, har.ld, dF_, B, Fmax, stft_variant, stream_);
+            tap("gen.har", har);
+            for (int st = 0; st < 2; ++st) {
+                const int ch = st == 0 ? 256 : 128;
+                auto S = [&](int C) { return st == 0 ? F20(C) : F121(C); };
+                ns[st] = S(ch);
+                T t1 = S(ch);
+                part_n[st] = (size_t)B * ch * ((st == 0 ? 20 * Fmax : 120 * Fmax + 1) / 64 + 4);  // >= tiles * WN
+                float2* part_t1 = static_cast<float2*>(A.alloc(part_n[st] * sizeof(float2)));
+                float2* part_xj = static_cast<float2*>(A.alloc(part_n[st] * sizeof(float2)));
+                {
+                    ConvOpts o;
+                    if (st == 0) { o.stride = 6; o.pad = 3; }
+                    o.stat_part = part_xj;
+                    conv(convs_.at(G + "noise_convs." + std::to_string(st)), har, ns[st], o);
+                }
+                adain_resblock1(G + "noise_res." + std::to_string(st), st == 0 ? 7 : 11, ns[st], ns[st], t1, ns[st], 0, 1.f,
+                                part_t1, part_xj);
+                tap(("gen.x_source." + std::to_string(st)).c_str(), ns[st]);
+                ev_ns[st] = record_here();
+            }
+        }
         // --- Decoder (istftnet.py Decoder.forward) ---
         T xcat0 = F1(514);
         if (!dry_)
@@ -1059,38 +1176,13 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
             adain_resblk("decoder.decode.3", *ci, g0, true, ua, ub, uc);
         }
         tap("dec.decode.3", g0);
-        // --- Generator: harmonic source -> STFT -> 2 up-sampling stages -> iSTFT head ---
-        const std::string G = "decoder.generator.";
-        const long hs_ld = (long)600 * Fmax;
-        float* har_src = A.f((size_t)B * hs_ld);
-        float* phase = A.f((size_t)B * 9 * 2 * Fmax);
-        if (!dry_)
-            launch_source(curves.p, curves.bs, dF_, B, Fmax, wt(G + "m_source.l_linear.weight"),
-                          wt(G + "m_source.l_linear.bias"), seed, utt_base, d_utt_seeds_, noise_off, phase, har_src, hs_ld, stream_);
-        if (taps_on_ && !dry_) {
-            T hs;
-            hs.p = har_src; hs.bs = hs_ld; hs.ld = (int)hs_ld; hs.C = 1; hs.len = LenMap{dF_, 600, 0}; hs.Lmax = 600 * Fmax;
-            tap("gen.har_source", hs);
-        }
-        T har = F121(22);
-        if (!dry_) launch_stft(har_src, hs_ld, har.p, har.bs, har.ld, dF_, B, Fmax, stft_variant, stream_);
-        tap("gen.har", har);
+        // --- Generator: 2 up-sampling stages -> iSTFT head (the harmonic source / noise path was issued above) ---
         T x = g0;
         for (int st = 0; st < 2; ++st) {
             const int ch = st == 0 ? 256 : 128;
             auto S = [&](int C) { return st == 0 ? F20(C) : F121(C); };
-            T ns = S(ch), xj = S(ch), t1 = S(ch), xu = S(ch), xs = S(ch);
-            const size_t part_n = (size_t)B * ch * ((st == 0 ? 20 * Fmax : 120 * Fmax + 1) / 64 + 4);  // >= tiles * WN
-            float2* part_t1 = static_cast<float2*>(A.alloc(part_n * sizeof(float2)));
-            float2* part_xj = static_cast<float2*>(A.alloc(part_n * sizeof(float2)));
-            {
-                ConvOpts o;
-                if (st == 0) { o.stride = 6; o.pad = 3; }
-                o.stat_part = part_xj;
-                conv(convs_.at(G + "noise_convs." + std::to_string(st)), har, ns, o);
-            }
-            adain_resblock1(G + "noise_res." + std::to_string(st), st == 0 ? 7 : 11, ns, ns, t1, ns, 0, 1.f, part_t1, part_xj);
-            tap(("gen.x_source." + std::to_string(st)).c_str(), ns);
+            T xu = S(ch), xs = S(ch);
+            wait_here(ev_ns[st]);
             {
                 ConvOpts o;  // x = ups(leaky_relu(x, 0.1)) (+ reflection pad on the last stage) + x_source
                 o.act = ACT_LEAKY; o.slope = 0.1f; o.pad = 1;
@@ -1099,14 +1191,27 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
                 o.up_off = st == 0 ? 0 : 1;
                 o.up_reflect = st == 0 ? 0 : 1;
                 o.up_len = st == 0 ? LF20 : LF120;
-                o.resid = &ns;
+                o.resid = &ns[st];
                 conv(convs_.at(G + "ups." + std::to_string(st)), x, xu, o);
             }
             tap(("gen.ups." + std::to_string(st)).c_str(), xu);
+            // The three resblocks (k = 3, 7, 11) read xu and are averaged: three independent chains, each on a lane of its
+            // own with its own scratch; only the last conv of a chain touches the shared running sum xs, in the fixed
+            // order k = 3, 7, 11 (events), so the result does not depend on how the chains interleave.  The raw
+            // InstanceNorm sums of xu are computed once, here, before the chains fork (stats() caches them per tensor).
             static const int ks[3] = {3, 7, 11};
-            for (int j = 0; j < 3; ++j)
-                adain_resblock1(G + "resblocks." + std::to_string(st * 3 + j), ks[j], xu, xj, t1, xs, j > 0 ? 1 : 0,
-                                j == 2 ? 3.0f : 1.0f, part_t1, part_xj);
+            const std::string RB = G + "resblocks.";
+            stats(xu, RB + std::to_string(st * 3 + 2) + ".adain1.0");
+            hipEvent_t ev_r = nullptr;
+            for (int j = 0; j < 3; ++j) {
+                T xj = S(ch), t1 = S(ch);
+                float2* p_t1 = static_cast<float2*>(A.alloc(part_n[st] * sizeof(float2)));
+                float2* p_xj = static_cast<float2*>(A.alloc(part_n[st] * sizeof(float2)));
+                LaneScope on_lane(*this, j == 2 ? 0 : j + 1);  // (the longest chain stays on the main stream)
+                adain_resblock1(RB + std::to_string(st * 3 + j), ks[j], xu, xj, t1, xs, j > 0 ? 1 : 0, j == 2 ? 3.0f : 1.0f,
+                                p_t1, p_xj, ev_r);
+                if (j < 2) ev_r = record_here();
+            }
             tap(("gen.stage." + std::to_string(st)).c_str(), xs);
             x = xs;
         }
@@ -1138,7 +1243,12 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     arenaF_.measure = false;
     const size_t needF = arenaF_.off;
     ensure_arena(arenaF_, needF);
-    back(arenaF_);
+    try {
+        back(arenaF_);
+    } catch (...) {
+        sync_lanes();  // (nothing of this call may still be running on a side lane when the arenas are handed out again)
+        throw;
+    }
 }
 
 void Model::set_voice_table(const float* table, int n_voices) {
@@ -1185,6 +1295,10 @@ void Model::infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* l
     KX_REQUIRE(hc.format >= 0 && hc.format <= 2, "infer: unknown output format");
     const bool by_voice = hc.voice_ids != nullptr;
     KX_REQUIRE(by_voice || hc.styles, "infer: styles or voice ids are required");
+    KX_REQUIRE(!hc.kinds || (by_voice && hc.styles), "infer: per-utterance kinds need both styles and voice ids");
+    auto kind_of = [&](int b) { return hc.kinds ? hc.kinds[b] : (by_voice ? (hc.max_mix == 1 ? 1 : 2) : 0); };
+    auto format_of = [&](int b) { return hc.formats ? hc.formats[b] : hc.format; };
+    auto bps_of = [&](int b) { return format_of(b) == 1 ? 8 : (format_of(b) == 2 ? 2 : 4); };
     if (by_voice) {
         KX_REQUIRE(d_voices_ && hc.weights && hc.max_mix >= 1 && hc.max_mix <= 16, "infer: voice table not set or bad mix");
     }
@@ -1194,7 +1308,8 @@ void Model::infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* l
             const int64_t id = ids[b * t_stride + t];
             KX_REQUIRE(id >= 0 && id < n_vocab_, "infer: token id outside 0..177");
         }
-        if (by_voice) {
+        KX_REQUIRE(kind_of(b) >= 0 && kind_of(b) <= 2 && format_of(b) >= 0 && format_of(b) <= 2, "infer: unknown kind / output format");
+        if (kind_of(b) != 0) {
             KX_REQUIRE(lens[b] >= 2, "infer: voice rows need the two 0 pads (row = tokens - 2)");
             bool any = false;
             for (int k = 0; k < hc.max_mix; ++k) {
@@ -1202,7 +1317,7 @@ void Model::infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* l
                 KX_REQUIRE(v < n_voices_, "infer: voice id outside the table");
                 any = any || v >= 0;
             }
-            KX_REQUIRE(any && (hc.max_mix > 1 || hc.voice_ids[(size_t)b * hc.max_mix] >= 0), "infer: no voice given");
+            KX_REQUIRE(any && (kind_of(b) != 1 || hc.voice_ids[(size_t)b * hc.max_mix] >= 0), "infer: no voice given");
         }
     }
     KX_HIP(hipSetDevice(device));
@@ -1211,7 +1326,7 @@ void Model::infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* l
     float* d_styles;
     int* d_fr;
     uint64_t* d_seeds;
-    int *d_vid, *d_rows;
+    int *d_vid, *d_rows, *d_kinds, *d_formats;
     float* d_w;
     void* d_packed;
     long* d_off;
@@ -1220,7 +1335,8 @@ void Model::infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* l
         ~SeedGuard() { p = nullptr; }
     } seed_guard{d_utt_seeds_};
     const int mm = by_voice ? hc.max_mix : 1;
-    const int bytes_per_sample = hc.format == 1 ? 8 : (hc.format == 2 ? 2 : 4);
+    int bytes_per_sample = 0;  // (the widest form of the batch sizes the packed buffer)
+    for (int b = 0; b < B; ++b) bytes_per_sample = bps_of(b) > bytes_per_sample ? bps_of(b) : bytes_per_sample;
     auto planIO = [&](Arena& A, size_t audio_floats) {
         A.off = 0;
         d_ids = static_cast<int64_t*>(A.alloc((size_t)B * t_stride * 8));
@@ -1229,6 +1345,8 @@ void Model::infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* l
         d_fr = A.i(B);
         d_vid = A.i((size_t)B * mm);
         d_rows = A.i(B);
+        d_kinds = A.i(B);
+        d_formats = A.i(B);
         d_w = A.f((size_t)B * mm);
         d_off = static_cast<long*>(A.alloc((size_t)B * 8));
         d_packed = A.alloc(audio_floats * bytes_per_sample);  // compact output: utterances back to back
@@ -1246,15 +1364,16 @@ void Model::infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* l
         ensure_arena(arenaIO_, need);
         float* d_audio = planIO(arenaIO_, (size_t)B * ld);
         KX_HIP(hipMemcpyAsync(d_ids, ids, (size_t)B * t_stride * 8, hipMemcpyHostToDevice, stream_));
+        if (hc.styles)  // (explicit rows first: the mix kernel then fills the rows of the utterances that name voices)
+            KX_HIP(hipMemcpyAsync(d_styles, hc.styles, (size_t)B * 256 * 4, hipMemcpyHostToDevice, stream_));
         if (by_voice) {
             std::vector<int> rows(B);
-            for (int b = 0; b < B; ++b) rows[b] = lens[b] - 2;  // tokens before the 0 padding (koko.rs:1161-1166)
+            for (int b = 0; b < B; ++b) rows[b] = lens[b] >= 2 ? lens[b] - 2 : 0;  // tokens before the 0 padding (koko.rs:1161-1166)
             KX_HIP(hipMemcpyAsync(d_vid, hc.voice_ids, (size_t)B * mm * 4, hipMemcpyHostToDevice, stream_));
             KX_HIP(hipMemcpyAsync(d_w, hc.weights, (size_t)B * mm * 4, hipMemcpyHostToDevice, stream_));
             KX_HIP(hipMemcpy(d_rows, rows.data(), (size_t)B * 4, hipMemcpyHostToDevice));
-            launch_style_mix(d_voices_, n_voices_, d_vid, d_w, mm, d_rows, d_styles, B, stream_);
-        } else {
-            KX_HIP(hipMemcpyAsync(d_styles, hc.styles, (size_t)B * 256 * 4, hipMemcpyHostToDevice, stream_));
+            if (hc.kinds) KX_HIP(hipMemcpy(d_kinds, hc.kinds, (size_t)B * 4, hipMemcpyHostToDevice));
+            launch_style_mix(d_voices_, n_voices_, d_vid, d_w, mm, d_rows, hc.kinds ? d_kinds : nullptr, d_styles, B, stream_);
         }
         d_utt_seeds_ = nullptr;
         if (hc.utt_seeds) {
@@ -1273,22 +1392,32 @@ void Model::infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* l
         }
         // frame counts are known (the forward's one host sync): pack the B waveforms back to back on the GPU in the
         // requested sample format, then ONE asynchronous copy into a page-locked host buffer
-        std::vector<long> off(B);
+        std::vector<long>& off = h_off_;
+        off.assign(B, 0);
         int64_t total = 0;
         for (int b = 0; b < B; ++b) {
             out_samples[b] = (int64_t)600 * hF_[b];
-            out_bytes[b] = out_samples[b] * bytes_per_sample;
+            out_bytes[b] = out_samples[b] * bps_of(b);
             off[b] = (long)total;
             total += out_bytes[b];
         }
         KX_HIP(hipMemcpyAsync(d_off, off.data(), (size_t)B * 8, hipMemcpyHostToDevice, stream_));
-        launch_pack_audio(d_audio, ld, dF_, B, Fmax_, hc.format, d_packed, 0, d_off, stream_);
+        if (hc.formats) KX_HIP(hipMemcpy(d_formats, hc.formats, (size_t)B * 4, hipMemcpyHostToDevice));
+        launch_pack_audio(d_audio, ld, dF_, B, Fmax_, hc.format, d_packed, 0, d_off, stream_, hc.formats ? d_formats : nullptr);
         char* host = static_cast<char*>(host_out_alloc((size_t)(total > 0 ? total : 1)));
         hipError_t e = hipMemcpyAsync(host, d_packed, (size_t)total, hipMemcpyDeviceToHost, stream_);
         if (e == hipSuccess) e = hipStreamSynchronize(stream_);
         if (e != hipSuccess) {
             host_out_free(host);
             throw Error(3, std::string("infer: D2H copy failed: ") + hipGetErrorString(e));
+        }
+        // the sticky device error word once more: kernels of the back half (the frame-axis LSTM) can raise it after the
+        // forward's mid-way check, and the audio of THIS call would be garbage -- it must fail here, not in the next call
+        try {
+            check_dev_err();
+        } catch (...) {
+            host_out_free(host);
+            throw;
         }
         *out = host;
         return;

@@ -80,6 +80,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_sync": (i32, [vp]),
         "kx_set_pinned_durations": (i32, [vp, vp, i32]),
         "kx_set_utterance_base": (i32, [vp, u64]),
+        "kx_set_lanes": (i32, [vp, i32]),
         "kx_set_conv_mode": (i32, [vp, i32]),
         "kx_get_conv_mode": (i32, [vp]),
         "kx_set_stft_variant": (i32, [vp, i32]),
@@ -98,7 +99,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_free_packed": (None, [vp]),
         "kx_dispatcher_create": (vp, [vp, i32, i32, i32, cp, sz]),
         "kx_dispatcher_submit": (i32, [vp, vp, i32, vp, f32, u64, C.POINTER(C.POINTER(f32)), C.POINTER(i64), cp, sz]),
+        "kx_dispatcher_submit_ex": (i32, [vp, vp, i32, vp, vp, vp, i32, f32, u64, i32, C.POINTER(vp), C.POINTER(i64),
+                                          C.POINTER(i64), cp, sz]),
         "kx_dispatcher_stats": (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+        "kx_dispatcher_model_batches": (i32, [vp, vp, i32]),
         "kx_dispatcher_destroy": (None, [vp]),
         "kx_debug_tap": (i32, [vp, cp, i32, vp, i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "kx_test_conv1d": (i32, [i32, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp,
@@ -106,6 +110,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_test_lstm": (i32, [i32, vp, i32, i32, i32] + [vp] * 9 + [cp, sz]),
         "kx_test_source": (i32, [i32, vp, i32, i32, vp, f32, u64, u64, i32, vp, cp, sz]),
         "kx_test_attention": (i32, [i32, vp, vp, i32, i32, vp, cp, sz]),
+        "kx_test_lstm_fault": (i32, [i32]),
         "kx_test_conv1d_epilogue": (i32, [i32, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, vp, i32, f32, f32, vp, vp,
                                           i32, cp, sz]),
     }
@@ -121,11 +126,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 ABI_SYMBOLS = [
     "kx_version", "kx_init", "kx_create", "kx_create_from_device_blob", "kx_create_replicas", "kx_destroy",
     "kx_last_error", "kx_last_error_copy", "kx_infer",
-    "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_set_utterance_base",
+    "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_set_utterance_base", "kx_set_lanes",
     "kx_set_conv_mode", "kx_get_conv_mode", "kx_set_stft_variant", "kx_get_stft_variant",
     "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_profile_aux", "kx_diag_enable", "kx_diag_count", "kx_diag_get", "kx_set_act_prescale", "kx_set_voice_table", "kx_infer_voices",
-    "kx_infer_packed", "kx_free_packed", "kx_dispatcher_create", "kx_dispatcher_submit",
-    "kx_dispatcher_stats", "kx_dispatcher_destroy", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test_attention", "kx_test_conv1d_epilogue",
+    "kx_infer_packed", "kx_free_packed", "kx_dispatcher_create", "kx_dispatcher_submit", "kx_dispatcher_submit_ex", "kx_dispatcher_model_batches",
+    "kx_dispatcher_stats", "kx_dispatcher_destroy", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test_attention", "kx_test_conv1d_epilogue", "kx_test_lstm_fault",
 ]
 
 
@@ -322,6 +327,11 @@ class HipKoko:
     def get_stft_variant(self) -> int:
         return int(self._lib.kx_get_stft_variant(self._h))
 
+    def set_lanes(self, n: int):
+        """1 = one stream; 4 = the independent chains of the back half side by side; 0 (default) = 4 up to batch 16,
+        else 1.  Bit-identical results for every value."""
+        self._check(self._lib.kx_set_lanes(self._h, n))
+
     def set_utterance_base(self, base: int):
         self._check(self._lib.kx_set_utterance_base(self._h, base))
 
@@ -420,10 +430,45 @@ class Dispatcher:
         finally:
             self._lib.kx_free_audio(out)
 
+    def submit_ex(self, ids: Sequence[int], style: Optional[Sequence[float]] = None,
+                  voices: Optional[Sequence] = None, speed: float = 1.0, seed: int = 0, fmt: int = 0) -> np.ndarray:
+        """The request as the reference's servers make it: `style` = the 256-float row, OR `voices` = one voice id
+        (int: single voice, row copy) or [(voice id, weight), ...] (a mix "a.4+b.5", koko.rs:1255-1306) into the
+        device voice table of every model; `fmt` = 0 f32 mono, 1 f32 stereo, 2 PCM16.  Returns the packed samples."""
+        a = np.ascontiguousarray(ids, dtype=np.int64)
+        st = vid = w = None
+        n_mix = 0
+        if style is not None:
+            st = _f32(np.asarray(style, dtype=np.float32).reshape(-1))
+            if st.shape[0] != STYLE_DIM:
+                raise ValueError(f"style row must have {STYLE_DIM} floats")
+        elif isinstance(voices, (int, np.integer)):
+            vid, n_mix = np.array([voices], dtype=np.int32), 1
+        else:
+            vid = np.array([v for v, _ in voices], dtype=np.int32)
+            w = np.array([x for _, x in voices], dtype=np.float32)
+            n_mix = len(vid)
+        out, nb, ns = C.c_void_p(), C.c_int64(0), C.c_int64(0)
+        err = C.create_string_buffer(256)
+        rc = self._lib.kx_dispatcher_submit_ex(self._d, _ptr(a), a.shape[0], _ptr(st), _ptr(vid), _ptr(w), n_mix,
+                                               float(speed), seed, fmt, C.byref(out), C.byref(nb), C.byref(ns), err, len(err))
+        if rc != 0:
+            raise KokoroxHipError(rc, err.value.decode())
+        try:
+            raw = C.string_at(out, nb.value)
+        finally:
+            self._lib.kx_free_audio(C.cast(out, C.POINTER(C.c_float)))
+        if fmt == 2:
+            return np.frombuffer(raw, dtype=np.int16).copy()
+        arr = np.frombuffer(raw, dtype=np.float32).copy()
+        return arr.reshape(-1, 2) if fmt == 1 else arr
+
     def stats(self):
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         self._lib.kx_dispatcher_stats(self._d, C.byref(a), C.byref(b), C.byref(c))
-        return {"requests": a.value, "batches": b.value, "max_batch": c.value}
+        per = (C.c_int64 * len(self._models))()
+        self._lib.kx_dispatcher_model_batches(self._d, per, len(self._models))
+        return {"requests": a.value, "batches": b.value, "max_batch": c.value, "batches_per_model": list(per)}
 
     def close(self):
         if getattr(self, "_d", None):

@@ -85,3 +85,78 @@ def test_replicas_share_one_file_read_and_serve_one_dispatcher(blob_path, hip_mo
         m.close()
     with pytest.raises(RuntimeError):
         hk.HipKoko.replicas(blob_path + ".missing", [0])
+
+
+def test_32_clients_mixed_voices_and_formats_over_two_models(blob_path, hip_model, oracle):
+    """BASELINE configs[4] as far as one GPU goes (kokorox-openai/src/lib.rs:370-439): 32 concurrent clients, the five
+    voice rules of the serving benchmark incl. "af_sky.4+af_nicole.5" named into the device voice table, explicit style
+    rows, all three output forms, two models behind one dispatcher.  Every request's bytes equal its solo call, both
+    models take batches (a waiting queue is split between the idle workers), and one request is checked against the
+    CPU oracle (not only against the HIP path itself)."""
+    from kokorox_amd import hip_koko as hk
+    from kokorox_amd import voices as V
+    from kokorox_amd import weights as W
+    from oracle import kokoro_ref as R
+    tab = W.synthetic_voices(4)
+    names = ("af_sky", "af_nicole", "am_adam", "bf_emma")
+    styles = {n: tab[i] for i, n in enumerate(names)}
+    rules = [("af_sky", 0), ("af_nicole", 1), ("af_sky.4+af_nicole.5", [(0, 4.0), (1, 5.0)]), ("am_adam", 2),
+             ("bf_emma.7+af_sky.3", [(3, 7.0), (0, 3.0)])]
+    ms = hk.HipKoko.replicas(blob_path, [0, 0])
+    for m in ms:
+        m.set_voice_table(tab)
+    hip_model.set_voice_table(tab)
+    hip_model.set_utterance_base(0)
+    n_clients, per = 32, 2
+    reqs = {}
+    for c in range(n_clients):
+        for j in range(per):
+            k = 6 + (7 * c + 3 * j) % 23
+            ids = R.synthetic_inputs(1, k, seed=700 + 10 * c + j)[0]
+            name, spec = rules[(c + j) % 5]
+            by_row = (c % 4 == 3)  # a quarter of the clients send the 256-float row (the host-side mixer's result)
+            reqs[(c, j)] = (ids, k, name, spec, by_row, (c + j) % 3, 5000 + 10 * c + j)
+    d = hk.Dispatcher(ms, max_batch=16, max_wait_us=30000)
+    out, errs = {}, []
+
+    def client(c):
+        try:
+            for j in range(per):
+                ids, k, name, spec, by_row, fmt, seed = reqs[(c, j)]
+                if by_row:
+                    out[(c, j)] = d.submit_ex(ids, style=V.mix_styles(styles, name, k)[0], seed=seed, fmt=fmt)
+                else:
+                    out[(c, j)] = d.submit_ex(ids, voices=spec, seed=seed, fmt=fmt)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=client, args=(c,)) for c in range(n_clients)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    st = d.stats()
+    # error isolation: a request that is wrong on its own fails alone; the dispatcher keeps serving
+    with pytest.raises(hk.KokoroxHipError, match="voice id"):
+        d.submit_ex(reqs[(0, 0)][0], voices=99, seed=1)
+    again = d.submit_ex(reqs[(0, 0)][0], voices=reqs[(0, 0)][3], seed=reqs[(0, 0)][6], fmt=reqs[(0, 0)][5])
+    d.close()
+    assert not errs, errs
+    assert st["requests"] == n_clients * per and st["batches"] < n_clients * per and st["max_batch"] > 1
+    assert all(b > 0 for b in st["batches_per_model"]), st  # both models worked
+    np.testing.assert_array_equal(again, out[(0, 0)])
+    for (c, j), (ids, k, name, spec, by_row, fmt, seed) in reqs.items():
+        row = V.mix_styles(styles, name, k)[0]
+        alone = hip_model.infer_packed([list(ids)], [row], [1.0], seed=seed, fmt=fmt)[0]
+        np.testing.assert_array_equal(out[(c, j)], alone, err_msg=f"client {c} request {j} ({name}, fmt {fmt})")
+    # one dispatched request against the oracle (f32 mono, a mix): durations exact, waveform under the usual protocol
+    c0 = next(key for key, v in reqs.items() if v[5] == 0 and v[2] == "af_sky.4+af_nicole.5" and not v[4])
+    ids, k, name, spec, by_row, fmt, seed = reqs[c0]
+    row = np.asarray(V.mix_styles(styles, name, k)[0], dtype=np.float32)
+    hip_model.infer([list(ids)], [list(row)], 1.0, seed=seed, flags=hk.KX_FLAG_TAPS)
+    f0, n_c, har = hip_model.tap("pred.F0", 0), hip_model.tap("pred.N", 0)[0], hip_model.tap("gen.har", 0)
+    audio, dur = oracle.forward(ids, row, 1.0, seed=seed, utt=0, f0_override=f0[0], n_override=n_c, har_override=har)
+    assert out[c0].shape[0] == 600 * int(dur.sum())
+    assert np.abs(out[c0] - audio.numpy()).max() < 1e-4
+    for m in ms:
+        m.close()

@@ -27,7 +27,7 @@ CONV_CASES = [
 ]
 
 
-MODES = [pytest.param(0, id="f32"), pytest.param(1, id="f16x3"), pytest.param(2, id="f16x3ws"), pytest.param(3, id="f16x3da")]
+MODES = [pytest.param(0, id="f32"), pytest.param(1, id="f16x3"), pytest.param(2, id="f16x3lds"), pytest.param(3, id="f16x3da")]
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -97,6 +97,63 @@ def test_bilstm(L, n_in):
           for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")]
     y = hk.lstm(x.float().numpy(), ps)
     assert np.abs(y - ref).max() < 1e-5
+
+
+def test_bilstm_more_pairs_than_cus():
+    """The two-CU recurrence at B = 130: 520 workgroups on 256 CUs, so halves wait for partners that are dispatched
+    later (blocks are dispatched in order and every poll is bounded); ragged lengths; no sticky error, f64 parity."""
+    from kokorox_amd import hip_koko as hk
+    torch.manual_seed(130)
+    B, L, n_in = 130, 11, 64
+    m = torch.nn.LSTM(n_in, 256, 1, batch_first=True, bidirectional=True).double()
+    x = torch.randn(B, L, n_in, dtype=torch.float64)
+    with torch.no_grad():
+        ref = m(x)[0].numpy()
+    ps = [getattr(m, n + suf).detach().float().numpy() for suf in ("", "_reverse")
+          for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")]
+    for _ in range(3):  # (several launches in a row: a stale exchange buffer would show)
+        y = hk.lstm(x.float().numpy(), ps)
+        assert np.abs(y - ref).max() < 1e-5
+
+
+def test_two_models_run_full_size_forwards_side_by_side(blob_path):
+    """Two models on one GPU, each running batch-32 forwards of 128-phoneme utterances from its own thread: their
+    two-CU LSTM launches contend for CUs (a half may wait for a partner that is queued behind the other model's
+    blocks).  No call may fail with a spurious KX_ERR_DEVICE, and both must equal the result of a quiet run."""
+    import threading
+    from kokorox_amd import hip_koko as hk
+    from kokorox_amd import weights as W
+    from oracle import kokoro_ref as R
+    B, n_ph = 32, 128
+    toks = [list(R.synthetic_inputs(1, n_ph, seed=900 + i)[0]) for i in range(B)]
+    voices = W.synthetic_voices(4)
+    styles = [voices[i % 4, n_ph, 0] for i in range(B)]
+    ms = hk.HipKoko.replicas(blob_path, [0, 0])
+    try:
+        for m in ms:
+            m.set_pinned_durations([3, 3, 3, 4])
+        quiet = ms[0].infer_batch(toks, styles, [1.0], seed=11)
+        res, errs = [None, None], []
+
+        def run(i):
+            try:
+                for _ in range(3):
+                    res[i] = ms[i].infer_batch(toks, styles, [1.0], seed=11)
+            except Exception as e:  # pragma: no cover
+                errs.append(e)
+
+        th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=600)
+        assert not errs, errs
+        for i in range(2):
+            for a, b in zip(res[i], quiet):
+                np.testing.assert_array_equal(a, b)
+    finally:
+        for m in ms:
+            m.close()
 
 
 def test_harmonic_source_phase_is_bit_faithful(oracle):
@@ -246,15 +303,51 @@ def test_direct_a_kernel_is_bit_identical_under_load(B, Cin, Cout, L, k, d):
     norm[:, 1] = 1.0 + 0.1 * norm[:, 1]
     p = d * (k - 1) // 2
     for kw in (dict(), dict(act=2, alpha=alpha, norm=norm)):
-        y1 = hk.conv1d(x, w, b, pad=p, dil=d, mode=1, **kw)
-        y3 = hk.conv1d(x, w, b, pad=p, dil=d, mode=3, **kw)
+        y2 = hk.conv1d(x, w, b, pad=p, dil=d, mode=2, **kw)   # LDS-DMA kernel forms only
+        y1 = hk.conv1d(x, w, b, pad=p, dil=d, mode=1, **kw)   # what the model launches (direct-A on this grid)
+        y3 = hk.conv1d(x, w, b, pad=p, dil=d, mode=3, **kw)   # direct-A forced
         assert np.isfinite(y3).all()
-        np.testing.assert_array_equal(y1, y3)
+        np.testing.assert_array_equal(y2, y3)
+        np.testing.assert_array_equal(y2, y1)
     res = rng.standard_normal(y1.shape, dtype=np.float32)
-    o1 = hk.conv1d_epilogue(x, w, b, pad=p, dil=d, resid=res, want_stats=True, mode=1)
+    o2 = hk.conv1d_epilogue(x, w, b, pad=p, dil=d, resid=res, want_stats=True, mode=2)
     o3 = hk.conv1d_epilogue(x, w, b, pad=p, dil=d, resid=res, want_stats=True, mode=3)
-    np.testing.assert_array_equal(o1[0], o3[0])
-    np.testing.assert_array_equal(o1[1], o3[1])
+    np.testing.assert_array_equal(o2[0], o3[0])
+    np.testing.assert_allclose(o2[1], o3[1], rtol=2e-6, atol=1e-3)  # (the partial sums may be added in another order)
+
+
+@pytest.mark.gpu
+def test_direct_a_run_time_tap_forms_are_bit_identical_under_load():
+    """The forms of the direct-A kernel that the resblock test above does not reach, on chip-filling launches, against the
+    LDS-DMA kernel: (a) a polyphase transposed conv (run-time tap count, two taps, scatter store), (b) a one-tap conv with
+    fewer than three 16-channel chunks (the ring's third slot is loaded but never consumed when there are fewer than three
+    steps), (c) the 128-column tile (NTT = 4) that small grids take."""
+    from kokorox_amd import hip_koko as hk
+    rng = np.random.default_rng(77)
+    # (a) ConvTranspose1d 256 -> 128, k = 12, stride 6 (generator ups.1) on 8 x 9000 columns
+    x = rng.standard_normal((8, 256, 9000), dtype=np.float32)
+    wt = (rng.standard_normal((256, 128, 12), dtype=np.float32) / np.sqrt(256 * 2)).astype(np.float32)
+    b = rng.standard_normal(128, dtype=np.float32)
+    ya = [hk.conv1d(x, wt, b, stride=6, pad=3, transposed=True, act=1, slope=0.1, mode=m) for m in (2, 1, 3)]
+    np.testing.assert_array_equal(ya[0], ya[1])
+    np.testing.assert_array_equal(ya[0], ya[2])
+    # (b) k = 1, 22 -> 128 channels (noise_convs.1: two chunks = two steps) on 8 x 30000 columns, and 40 -> 128 with leaky
+    for cin, kw in ((22, dict()), (40, dict(act=1, slope=0.2))):
+        x = rng.standard_normal((8, cin, 30000), dtype=np.float32)
+        w = (rng.standard_normal((128, cin, 1), dtype=np.float32) / np.sqrt(cin)).astype(np.float32)
+        yb = [hk.conv1d(x, w, b, mode=m, **kw) for m in (2, 1, 3)]
+        np.testing.assert_array_equal(yb[0], yb[1])
+        np.testing.assert_array_equal(yb[0], yb[2])
+    # (c) 128-column tiles: a grid under 256 workgroups takes NTT = 4 in mode 1 (B = 1, 128 -> 128, k = 7 on 25000 columns
+    # = 98 tiles of 256), several launches back to back
+    x = rng.standard_normal((1, 128, 25000), dtype=np.float32)
+    w = (rng.standard_normal((128, 128, 7), dtype=np.float32) / np.sqrt(128 * 7)).astype(np.float32)
+    alpha = (0.5 + rng.random(128)).astype(np.float32)
+    norm = rng.standard_normal((1, 3, 128), dtype=np.float32)
+    y2 = hk.conv1d(x, w, b, pad=9, dil=3, act=2, alpha=alpha, norm=norm, mode=2)
+    for _ in range(3):
+        y1 = hk.conv1d(x, w, b, pad=9, dil=3, act=2, alpha=alpha, norm=norm, mode=1)
+        np.testing.assert_array_equal(y2, y1)
 
 
 @pytest.mark.gpu

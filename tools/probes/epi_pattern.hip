@@ -1,0 +1,180 @@
+// Probe: what does the conv epilogue's memory ACCESS PATTERN cost beside MFMA work, per CU?
+//
+// One workgroup = 4 waves, each owning 32 rows x 256 columns of f32 accumulators (the direct-A conv's tile), two
+// workgroups per CU.  Phase M: `iters` steps of 8 column tiles x 3 MFMAs on register operands (no memory at all).
+// Phase E: out = acc * scale + bias + resid, in one of three access patterns:
+//   0  the shipped epilogue (conv_epilogue.h: one dword per lane, an instruction = 2 rows x 128 B, residual loads two
+//      batches ahead of the stores)
+//   1  "row per lane": accumulators as the TRANSPOSED MFMA leaves them (lane = row, four consecutive columns in four
+//      consecutive registers): 16 B per lane, an instruction = 32 rows x 32 B
+//   2  full lines through LDS: the transposed accumulators go through an LDS transpose so that an instruction is
+//      8 rows x 128 B, 16 B per lane (8 lanes per line)
+// Footprint: streaming (every workgroup its own 128 KiB of y and of resid: HBM) or hot (64 tiles shared: cache).
+// Prints ms per launch for M only, E only and M + E.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../kokorox_amd/csrc/conv_epilogue.h"
+
+using namespace kx;
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int PAT>
+__global__ __launch_bounds__(256, 2) void probe(ConvArgs a, int iters, int do_e, int hot, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[1][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][j][e] = (float)(lane + e + j) * 1e-3f;
+    half8 fa, fb;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        fa[i] = (_Float16)(0.01f * (lane + i));
+        fb[i] = (_Float16)(0.02f * (lane - i));
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[0][n], 0, 0, 0);
+            acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fa, acc[0][n], 0, 0, 0);
+            acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fa, acc[0][n], 0, 0, 0);
+        }
+    }
+    if (!do_e) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s += acc[0][j][e];
+        if (s == 123.456f) sink[0] = s;
+        return;
+    }
+    const int b = blockIdx.z;
+    const int tile_x = hot ? (int)((blockIdx.x + blockIdx.z * gridDim.x) & 63u) : (int)blockIdx.x;
+    const int bb = hot ? 0 : b;
+    const int t0 = tile_x * 256;
+    if constexpr (PAT == 0) {
+        float2* scr = reinterpret_cast<float2*>(smem) + wave * (32 * 33);
+        conv_store_tile<1, 4, 4, false>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][0]), a.w_unscale, bb, wave * 32, t0, r, h,
+                                        a.y_ld, a.y_ld, 0, scr);
+        conv_store_tile<1, 4, 4, false>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][4]), a.w_unscale, bb, wave * 32, t0 + 128, r,
+                                        h, a.y_ld, a.y_ld, 0, scr);
+    } else if constexpr (PAT == 1) {
+        // lane = row r of the wave's 32; registers 4q..4q+3 of a tile = columns 8q + 4h .. +3
+        float* yb = a.y + (long)bb * a.y_bs + (long)(wave * 32 + r) * a.y_ld + t0 + 4 * h;
+        const float* rb = a.resid + (long)bb * a.r_bs + (long)(wave * 32 + r) * a.r_ld + t0 + 4 * h;
+        const float bias = a.bias[wave * 32 + r];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 rv[4][4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rv[n][q] = *reinterpret_cast<const f32x4*>(rb + (half * 4 + n) * 32 + 8 * q);
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(acc[0][half * 4 + n][4 * q + i], a.w_unscale, bias) + rv[n][q][i];
+                    *reinterpret_cast<f32x4*>(yb + (half * 4 + n) * 32 + 8 * q) = v;
+                }
+        }
+    } else {
+        // LDS transpose per 32 x 32 tile: write lane (row r, cols 8q+4h..+3) as 16 B at [row][col], pitch 36 floats;
+        // read back lane' = (row 8i + (lane >> 3), piece lane & 7): 16 B at [row][4 piece]
+        float* scr = reinterpret_cast<float*>(smem) + wave * (32 * 36);
+        const int rr = lane >> 3, pc = lane & 7;
+        float* yb = a.y + (long)bb * a.y_bs + (long)(wave * 32 + rr) * a.y_ld + t0 + 4 * pc;
+        const float* rb = a.resid + (long)bb * a.r_bs + (long)(wave * 32 + rr) * a.r_ld + t0 + 4 * pc;
+        float bias4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias4[i] = a.bias[wave * 32 + 8 * i + rr];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 rv[4][4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    rv[n][i] = *reinterpret_cast<const f32x4*>(rb + (long)(8 * i) * a.r_ld + (half * 4 + n) * 32);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = acc[0][half * 4 + n][4 * q + i];
+                    *reinterpret_cast<f32x4*>(scr + r * 36 + 8 * q + 4 * h) = v;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(scr + (8 * i + rr) * 36 + 4 * pc);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = __builtin_fmaf(v[c], a.w_unscale, bias4[i]) + rv[n][i][c];
+                    *reinterpret_cast<f32x4*>(yb + (long)(8 * i) * a.y_ld + (half * 4 + n) * 32) = v;
+                }
+            }
+        }
+    }
+}
+
+template <int PAT>
+static float run(const ConvArgs& a, dim3 grid, int iters, int do_e, int hot, float* sink, int reps) {
+    const size_t lds = PAT == 2 ? 4 * 32 * 36 * 4 : 4 * 32 * 33 * 8;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(probe<PAT>, grid, dim3(256), lds, 0, a, iters, do_e, hot, sink);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(probe<PAT>, grid, dim3(256), lds, 0, a, iters, do_e, hot, sink);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms / reps;
+}
+
+int main(int argc, char** argv) {
+    const int B = 64, L = 50688, C = 128;  // the 128-channel stage-1 tensor of the bench workload (198 column tiles)
+    const int iters = argc > 1 ? atoi(argv[1]) : 88;
+    float *y, *res, *bias, *sink;
+    const size_t n = (size_t)B * C * L;
+    hipMalloc(&y, n * 4);
+    hipMalloc(&res, n * 4);
+    hipMalloc(&bias, C * 4);
+    hipMalloc(&sink, 64);
+    hipMemset(y, 0, n * 4);
+    hipMemset(res, 0, n * 4);
+    hipMemset(bias, 0, C * 4);
+    ConvArgs a{};
+    a.y = y; a.y_bs = (long)C * L; a.y_ld = L;
+    a.resid = res; a.r_bs = (long)C * L; a.r_ld = L;
+    a.bias = bias; a.Cout = C; a.out_mul = 1.f; a.out_div = 1.f; a.w_unscale = 0.5f; a.store = ST_NORMAL;
+    dim3 grid(L / 256, 1, B);
+    const double bytes = 2.0 * n * 4;
+    printf("grid %d x %d workgroups, %d MFMA steps per tile, %.2f GB moved by a streaming epilogue\n", grid.x, grid.z, iters, bytes / 1e9);
+    const float m_only = run<0>(a, grid, iters, 0, 0, sink, 5);
+    printf("M only: %.3f ms\n", m_only);
+    const char* names[3] = {"dword, 2 rows x 128 B (shipped)", "row per lane, 32 rows x 32 B", "full lines via LDS, 8 rows x 128 B"};
+    for (int hot = 0; hot < 2; ++hot) {
+        for (int p = 0; p < 3; ++p) {
+            float e_only, both;
+            if (p == 0) { e_only = run<0>(a, grid, 0, 1, hot, sink, 5); both = run<0>(a, grid, iters, 1, hot, sink, 5); }
+            else if (p == 1) { e_only = run<1>(a, grid, 0, 1, hot, sink, 5); both = run<1>(a, grid, iters, 1, hot, sink, 5); }
+            else { e_only = run<2>(a, grid, 0, 1, hot, sink, 5); both = run<2>(a, grid, iters, 1, hot, sink, 5); }
+            printf("%-8s %-38s E only %.3f ms (%.2f TB/s)   M + E %.3f ms   exposed %.3f ms\n", hot ? "hot" : "stream", names[p],
+                   e_only, bytes / e_only / 1e9, both, both - m_only);
+        }
+    }
+    return 0;
+}
