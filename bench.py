@@ -306,6 +306,8 @@ def main():
     ap.add_argument("--detail", default="", help="write a per-shape table of the conv launches to this file")
     ap.add_argument("--free-run", type=int, default=1, help="also time one step with predicted durations")
     ap.add_argument("--pcie", type=int, default=1, help="also time one step through the host-buffer boundary (N=1)")
+    ap.add_argument("--reduced", type=int, default=1,
+                    help="also time the opt-in reduced-precision mode (one f16 MFMA per product) as a secondary block (N=1)")
     ap.add_argument("--serve", type=int, default=1, help="also run the 32-client serving leg (configs[4]) on rank 0 at N=1")
     ap.add_argument("--replicas", type=int, default=0,
                     help="single-process form: N models from kx_create_replicas, one host thread each (instead of torchrun)")
@@ -480,6 +482,39 @@ def main():
                         "D2H into pooled page-locked host memory, kx_free_audio"}
         progress(f"host-buffer step: {w2:.3f} s")
 
+    # ---- secondary: the opt-in reduced-precision mode (BASELINE configs[2] says "bf16"; the reference's model_fp16 /
+    # quantised variants, hf_cache.rs:135-144).  Never `value`: narrower than the reference's fp32 default. ----
+    reduced = None
+    if a.reduced and rank == 0 and world == 1 and f16x3:
+        model.set_pinned_durations([3, 3, 3, 4])
+        model.set_utterance_base(rank * B)
+        model.set_conv_mode(4)
+        try:
+            step()
+            model.sync()
+            model.profile_enable(True)
+            t3 = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            fence()
+            w3 = time.perf_counter() - t3
+            n3, ms3, fl3 = model.profile_read()
+            model.profile_enable(False)
+            det3 = model.profile_detail()
+            # the launches that actually ran one MFMA per product: the stride-1 128-row convs of decoder and generator
+            ach3 = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
+            reduced = {"mode": "KOKOROX_CONV=f16: one v_mfma_f32_32x32x16_f16 per product in the decoder / generator convs of the "
+                               "direct-A kernel (f16 operands, f32 accumulate); duration head, F0/N predictor, source, STFT f32-class",
+                       "value": audio_s_per_step * a.steps / w3, "unit": "x realtime", "ms_per_step": w3 / a.steps * 1e3,
+                       "roofline": {"bound": "mfma", "achieved": ach3, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": ach3 / PEAK_F16_MFMA_TFLOPS, "mfma_issue_factor": "1 on the direct-A convs, 3 elsewhere",
+                                    "avg_launch_ms": ms3 / max(n3, 1), "launches_per_step": n3 / max(a.steps, 1)},
+                       "note": "secondary figure; waveform error vs the oracle is measured in tests/test_gpu_forward.py "
+                               "(test_reduced_precision_mode_error_is_bounded)"}
+            progress(f"reduced-precision steps: {w3:.3f} s")
+        finally:
+            model.set_conv_mode(1)
+
     if rank == 0:
         flops_per_utt = (0.1635 * T + 1.317 * F) * 1e9  # SURVEY.md §8d model
         out = {
@@ -512,6 +547,7 @@ def main():
             "in_stats": {"launches_per_step": stats_launches / max(a.steps, 1), "bytes_per_step": stats_bytes / max(a.steps, 1)},
             "free_running": free,
             "pcie_inclusive": pcie,
+            "reduced_precision": reduced,
         }
         out["serve"] = serve_leg([model]) if (world == 1 and a.serve) else None
         if world == 1 and a.cpu_utts > 0:

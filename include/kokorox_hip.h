@@ -121,7 +121,12 @@ int kx_set_pinned_durations(kx_model* m, const int32_t* pattern, int n);
 
 /* Contraction arithmetic of the conv/linear kernel: 0 = f32 MFMA (v_mfma_f32_32x32x2_f32, exact f32
  * products), 1 = f16x3 split MFMA (three v_mfma_f32_32x32x16_f16 per K-step on hi/lo halves, ~22
- * significant bits per product, f32 accumulation).  Default 1; env KOKOROX_CONV=f32 selects 0 at create. */
+ * significant bits per product, f32 accumulation).  Default 1; env KOKOROX_CONV=f32 selects 0 at create.
+ * 4 = reduced precision, opt-in (env KOKOROX_CONV=f16): the decoder / generator convs of the direct-A kernel issue ONE
+ * f16 MFMA per product (weights and activations rounded to f16, f32 accumulation) -- the library's counterpart of the
+ * reference's `model_fp16` / quantised variants run at their own precision (kokorox/src/utils/hf_cache.rs:135-144) and
+ * of BASELINE configs[2] "bf16"; duration head, F0 / N predictor, harmonic source and STFT pair stay f32-class.  Never
+ * the default: the waveform leaves the 1e-4 parity band (measured bound in tests/test_gpu_forward.py). */
 int kx_set_conv_mode(kx_model* m, int mode);
 int kx_get_conv_mode(kx_model* m);
 

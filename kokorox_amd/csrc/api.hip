@@ -280,7 +280,8 @@ int kx_set_pinned_durations(kx_model* m, const int32_t* pattern, int n) {
 
 int kx_set_conv_mode(kx_model* m, int mode) {
     return guarded(m, [&](Model& M) {
-        KX_REQUIRE(mode == kx::CONV_F32 || mode == kx::CONV_F16X3, "conv mode must be 0 (f32 MFMA) or 1 (f16x3 split MFMA)");
+        KX_REQUIRE(mode == kx::CONV_F32 || mode == kx::CONV_F16X3 || mode == kx::CONV_F16,
+                   "conv mode must be 0 (f32 MFMA), 1 (f16x3 split MFMA) or 4 (f16, reduced precision)");
         M.sync();
         M.conv_mode = mode;
     });

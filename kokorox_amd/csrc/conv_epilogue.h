@@ -254,6 +254,105 @@ __device__ __forceinline__ void conv_store_rmw(const ConvArgs& a, f32x16 (&acc)[
     }
 }
 
+// ---- wide form of the read-modify-write store (direct-A kernels, interior 32-row x 128-column groups) ----------------------
+// Measured (profiles/r03_epi_pattern_probe.txt): the dword form above issues 2 rows x 128 B per instruction; the same bytes
+// moved as whole 128-byte lines, 16 B per lane (8 rows x 128 B per instruction), issue 1.75x faster and halve what the
+// epilogue exposes beside MFMA work.  A lane cannot do that from the MFMA C/D layout (it holds ONE column of a tile), so
+// every 32 x 32 tile goes through a 4 KiB LDS transpose: 16 ds_write_b32 (register e = rows (e&3)+8(e>>2)+4h, one column per
+// lane: 2 rows x 32 floats per instruction, conflict-free at a pitch of 32 floats), then 4 ds_read_b128 in the store layout:
+// lane' = (row 8 i + (lane >> 3), columns 4 (lane & 7) .. + 3), also conflict-free.  LDS operations of one wave execute in
+// order, so the scratch needs no barrier.  Residual / running-sum loads use the same layout and need no transpose; they are
+// issued one unit (two tiles; one when there are two loads per element) ahead of the stores, which come later in the wave's
+// in-order memory queue.  Per element the arithmetic is that of conv_store_rmw, operation for operation (the stored values
+// are bit-identical); the InstanceNorm partial sums are added in another order (4 columns per lane, 8 lanes per row, DPP),
+// which both tile widths of the direct-A kernel share (batch invariance).
+template <int LOADS>
+__device__ __forceinline__ void conv_store_wide4(const ConvArgs& a, f32x16 (&acc)[1][4], float acc_scale, int b, int row0,
+                                                 int col0, int lane, int stat_slot, float* scr) {
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    const int r = lane & 31, h = lane >> 5;
+    const int rr = lane >> 3, pc = lane & 7;  // store layout: row 8 i + rr of the wave's 32, 16-byte piece pc of a tile row
+    const bool want_stats = a.stat_part != nullptr;
+    const buf_rsrc ybuf = make_buf(a.y + (long)b * a.y_bs);
+    const buf_rsrc rbuf = make_buf(LOADS >= 1 ? a.resid + (long)b * a.r_bs : a.y);
+    const unsigned ylane = 4u * ((unsigned)rr * (unsigned)a.y_ld + 4u * (unsigned)pc);
+    const unsigned rlane = 4u * ((unsigned)rr * (unsigned)a.r_ld + 4u * (unsigned)pc);
+    auto yterm = [&](int n, int i) { return 4u * ((unsigned)(row0 + 8 * i) * (unsigned)a.y_ld + (unsigned)(col0 + 32 * n)); };
+    auto rterm = [&](int n, int i) { return 4u * ((unsigned)(row0 + 8 * i) * (unsigned)a.r_ld + (unsigned)(col0 + 32 * n)); };
+    auto ld4 = [&](buf_rsrc rs, unsigned lane_off, unsigned uni) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, uni, KX_EPI_LD_AUX));
+    };
+    float bias4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias4[i] = a.bias ? a.bias[row0 + 8 * i + rr] : 0.f;
+    const float div_d = a.out_div, div_rd = 1.0f / a.out_div;
+    constexpr int UT = LOADS == 2 ? 1 : 2;  // tiles per load unit
+    constexpr int NU = 4 / UT;
+    f32x4 rv[2][UT][4], yv[2][LOADS == 2 ? UT : 1][4];
+    auto load_unit = [&](int u, f32x4 (&rvu)[UT][4], f32x4 (&yvu)[LOADS == 2 ? UT : 1][4]) {
+#pragma unroll
+        for (int t = 0; t < UT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rvu[t][i] = ld4(rbuf, rlane, rterm(u * UT + t, i));
+                if (LOADS == 2) yvu[t][i] = ld4(ybuf, ylane, yterm(u * UT + t, i));
+            }
+    };
+    if (LOADS >= 1) load_unit(0, rv[0], yv[0]);
+    float rs[4] = {0.f, 0.f, 0.f, 0.f}, rq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        if (LOADS >= 1 && u + 1 < NU) load_unit(u + 1, rv[(u + 1) & 1], yv[(u + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < UT; ++t) {
+            const int n = u * UT + t;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) scr[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[0][n][e];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(scr + (8 * i + rr) * 32 + 4 * pc);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float x = __builtin_fmaf(v[c], acc_scale, bias4[i]);
+                    if (LOADS >= 1) x += rv[u & 1][t][i][c];
+                    if (LOADS == 2) x += yv[u & 1][t][i][c];
+                    x *= a.out_mul;
+                    if (LOADS == 2) x = div_const(x, div_d, div_rd);
+                    v[c] = x;
+                    rs[i] += x;
+                    rq[i] = __builtin_fmaf(x, x, rq[i]);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ybuf, ylane,
+                                                       yterm(n, i), KX_EPI_ST_AUX);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (want_stats) {
+        // a row's partial lives in its 8 lanes (pieces 0..7): xor-1, xor-2 (quad_perm), then the mirror inside each half row
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float s = rs[i], q = rq[i];
+            s = dpp_add<0xB1>(s);
+            q = dpp_add<0xB1>(q);
+            s = dpp_add<0x4E>(s);
+            q = dpp_add<0x4E>(q);
+            s = dpp_add<0x141>(s);  // row_half_mirror: lane j <-> 7 - j inside each group of 8
+            q = dpp_add<0x141>(q);
+            if (pc == 0)
+                a.stat_part[((long)b * a.Cout + row0 + 8 * i + rr) * a.stat_tiles + stat_slot] = make_float2(s, q);
+        }
+    }
+}
+
+// Dispatcher of the direct-A kernels for one 32-row x 128-column group: the wide form where it applies (plain channel-major
+// store, the whole group inside the tensor), else the general forms below.
+template <int EB>
+__device__ __forceinline__ void conv_store_group(const ConvArgs& a, f32x16 (&acc)[1][4], float acc_scale, int b, int row0,
+                                                 int col0, int r, int h, int ncols, int Lout, int stat_slot, float2* stat_scr,
+                                                 float* wide_scr);
+
 // EB = rows per load batch of the read-modify-write path
 template <int MT, int NT, int EB, bool GELU>
 __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)[MT][NT], float acc_scale, int b,
@@ -366,6 +465,33 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)
             }
         }
     }
+}
+
+#ifndef KX_EPI_WIDE
+#define KX_EPI_WIDE 1
+#endif
+template <int EB>
+__device__ __forceinline__ void conv_store_group(const ConvArgs& a, f32x16 (&acc)[1][4], float acc_scale, int b, int row0,
+                                                 int col0, int r, int h, int ncols, int Lout, int stat_slot, float2* stat_scr,
+                                                 float* wide_scr) {
+    const bool full = row0 + 32 <= a.Cout && col0 + 128 <= ncols;  // wave-uniform
+    if (KX_EPI_WIDE && a.store == ST_NORMAL && full && a.merge_T == 0 && !(a.dbg & 16384)) {
+        const int lane = r + 32 * h;
+        const bool res = a.resid != nullptr, accum = a.accum != 0;
+        if (res && accum) {
+            conv_store_wide4<2>(a, acc, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
+            return;
+        }
+        if (res && !accum) {
+            conv_store_wide4<1>(a, acc, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
+            return;
+        }
+        if (!res && !accum) {
+            conv_store_wide4<0>(a, acc, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
+            return;
+        }
+    }
+    conv_store_tile<1, 4, EB, false>(a, acc, acc_scale, b, row0, col0, r, h, ncols, Lout, stat_slot, stat_scr);
 }
 
 }  // namespace kx

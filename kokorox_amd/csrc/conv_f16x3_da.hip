@@ -45,6 +45,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+#ifndef KX_DA_P1
 bool conv16_da_eligible(int BM, int K, int dil, int stride, int merged) {
     return BM == 128 && stride == 1 && !merged && (K - 1) * dil + 256 <= 384;
 }
@@ -52,8 +53,12 @@ bool conv16_use_da(int BM, int K, int dil, int stride, int merged) {
     static const int on = getenv("KX_DA") ? atoi(getenv("KX_DA")) : 1;
     return on && conv16_da_eligible(BM, K, dil, stride, merged);
 }
+#endif
 
-template <int ACT, int KT, int NTT>
+// P1: the opt-in reduced-precision form (KOKOROX_CONV=f16, BASELINE configs[2] "bf16" / the reference's model_fp16
+// variants, hf_cache.rs:135-144): ONE v_mfma_f32_32x32x16_f16 per product on the high halves only (weights and activations
+// rounded to f16, f32 accumulation); the low halves are neither loaded, nor computed, nor read.
+template <int ACT, int KT, int NTT, bool P1>
 __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(const ConvArgs a) {
     // NTT = 8: the 128 x 256 tile of chip-filling launches; NTT = 4: 128 x 128 for small grids (batch 1), three workgroups per CU
     constexpr int BM = 128, NT = NTT, BN = 32 * NT;
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
             split_pair(y2[0], y2[1], hp[c2], lp[c2]);
         }
         Xb[(0 * 2 + g) * XWp + u] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
-        Xb[(1 * 2 + g) * XWp + u] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+        if constexpr (!P1) Xb[(1 * 2 + g) * XWp + u] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
     };
     auto stage_from_raw = [&](uint4* Xb, int ch) __attribute__((always_inline)) {
         Oct o;
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
             const int u = lane + 64 * (jb + 2 * j);
             unsigned* Xw = reinterpret_cast<unsigned*>(Xb);
             Xw[((0 * 2 + g) * XWp + u) * 4 + c2] = hp;
-            Xw[((1 * 2 + g) * XWp + u) * 4 + c2] = lp;
+            if constexpr (!P1) Xw[((1 * 2 + g) * XWp + u) * 4 + c2] = lp;
         }
     };
 
@@ -282,8 +287,9 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         const int sc = s < n_steps ? s : n_steps - 1;  // (only the three loads of the prologue can point past the end)
         const uint4* p = wlane + (long)sc * tap_units;
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a_hi) : "v"(p) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a_lo) : "v"(p + 2 * BM) : "memory");
+        if constexpr (!P1) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a_lo) : "v"(p + 2 * BM) : "memory");
     };
+    constexpr int APL = P1 ? 1 : 2;  // vector loads per ring refill (what the hand-counted waits add per refill)
     // wait until at most `age` (rounded down to a value this switch knows) vector-memory operations are outstanding.
     // The compiler takes the result of a load asm for complete the moment the asm is issued, so nothing may touch the
     // fragments before this wait: the wait has no operands (a tied "+v" operand made the register allocator copy the
@@ -306,7 +312,8 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         else if (age >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" : "+v"(a_hi), "+v"(a_lo));
+        if constexpr (P1) asm volatile("" : "+v"(a_hi));
+        else asm volatile("" : "+v"(a_hi), "+v"(a_lo));
     };
     // vector loads of one load_raw(): exact counting is worth 2 % of the step against counting the asm loads only (always
     // a safe under-estimate: 123.8 vs 126.2 ms)
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     // Three-deep A ring with STATIC slots: step s uses slot s % 3 and refills it for step s + 3 as soon as its MFMAs are
     // issued, so a fragment is requested two whole steps before its use and nothing ever moves between registers.  The
     // (chunk, tap) walk is flattened and unrolled by three for that.
-    u32x4 ah0, al0, ah1, al1, ah2, al2;
+    u32x4 ah0, al0 = {0, 0, 0, 0}, ah1, al1 = {0, 0, 0, 0}, ah2, al2 = {0, 0, 0, 0};
     load_A(0, ah0, al0);
     load_A(1, ah1, al1);
     // (a slot that is never consumed must never be loaded: its asm result is dead to the compiler, which hands the registers
@@ -356,15 +363,15 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         u32x4 ahs[4] = {ah0, ah1, ah2, ah2}, als[4] = {al0, al1, al2, al2};
         if constexpr (R == 4) {
             load_A(3, ahs[3], als[3]);
-            ages[0] += 2;
-            ages[1] += 2;
-            ages[2] += 2;
+            ages[0] += APL;
+            ages[1] += APL;
+            ages[2] += APL;
         }
         half8 fh[3], fl[3];
         auto load_tile = [&](int t, int n, half8& fhx, half8& flx) __attribute__((always_inline)) {
             const uint4* xt = Xs + cur * XBUF + h * XWp + r + t * dil + n * 32;
             fhx = *reinterpret_cast<const half8*>(xt);
-            flx = *reinterpret_cast<const half8*>(xt + 2 * XWp);
+            if constexpr (!P1) flx = *reinterpret_cast<const half8*>(xt + 2 * XWp);
         };
         load_tile(0, 0, fh[0], fl[0]);
         if constexpr (BR == 3) load_tile(0, 1, fh[1], fl[1]);
@@ -387,8 +394,10 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
                 const half8 ah = __builtin_bit_cast(half8, ahs[sl]), al = __builtin_bit_cast(half8, als[sl]);
                 if constexpr (ip < TILES) load_tile(ip / NT, ip % NT, fh[e2], fl[e2]);
                 __builtin_amdgcn_sched_barrier(0);
-                acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fh[e], acc[0][n], 0, 0, 0);
-                acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fl[e], acc[0][n], 0, 0, 0);
+                if constexpr (!P1) {
+                    acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fh[e], acc[0][n], 0, 0, 0);
+                    acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fl[e], acc[0][n], 0, 0, 0);
+                }
                 acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fh[e], acc[0][n], 0, 0, 0);
                 // half-units [h0, h1) of the next chunk's transform ride on this tile (in the last chunk they run on
                 // stale registers into the image nobody reads: cheaper than a second version of the loop)
@@ -407,7 +416,9 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
                     xform_c((h0 + 1) / 2, (h0 + 1) & 1, Xs + (cur ^ 1) * XBUF, ch + 1);
                 }
                 static_assert(h1 - h0 <= 2, "at most two half-units per tile");
-                if constexpr (h1 - h0 == 1) {
+                if constexpr (P1) {  // (one MFMA per tile: the vector work follows it in one piece)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                } else if constexpr (h1 - h0 == 1) {
 #pragma unroll
                     for (int k3 = 0; k3 < 3; ++k3) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
@@ -428,7 +439,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
                     if (t + R < KT || (more && sl < KT)) {
                         load_A(nxt, ahs[sl], als[sl]);
 #pragma unroll
-                        for (int o = 0; o < R; ++o) ages[o] = o == sl ? 0 : ages[o] + 2;
+                        for (int o = 0; o < R; ++o) ages[o] = o == sl ? 0 : ages[o] + APL;
                     }
                 }
             });
@@ -455,7 +466,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     auto load_tile = [&](int t, int n, half8& fhx, half8& flx) __attribute__((always_inline)) {
         const uint4* xt = Xs + cur * XBUF + h * XWp + r + t * dil + n * 32;
         fhx = *reinterpret_cast<const half8*>(xt);
-        flx = *reinterpret_cast<const half8*>(xt + 2 * XWp);
+        if constexpr (!P1) flx = *reinterpret_cast<const half8*>(xt + 2 * XWp);
     };
     load_tile(0, 0, fh[0], fl[0]);
     load_tile(0, 1, fh[1], fl[1]);
@@ -479,8 +490,10 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
             // (the transform stays at the chunk boundary in this form: its parts placed behind these MFMAs in blocks guarded
             // by a wave-uniform flag were measured 2 % SLOWER than the plain loop -- two taken branches per tile in the
             // rounds without a transform; the unrolled form above needs no guards)
-            acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fh[e], acc[0][n], 0, 0, 0);
-            acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fl[e], acc[0][n], 0, 0, 0);
+            if constexpr (!P1) {
+                acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fh[e], acc[0][n], 0, 0, 0);
+                acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fl[e], acc[0][n], 0, 0, 0);
+            }
             acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fh[e], acc[0][n], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -489,8 +502,8 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         if (sidx + 3 < n_steps) {
             load_A(sidx + 3, ahx, alx);
             age = 0;
-            o1 += 2;
-            o2 += 2;
+            o1 += APL;
+            o2 += APL;
         }
         if (++tt == K) {  // chunk boundary
             tt = 0;
@@ -530,20 +543,29 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     // the statistics scratch of the epilogue lives in the input buffers: everybody must be done reading them
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     float2* stat_scr = reinterpret_cast<float2*>(smem16) + wave * (32 * 33);
+    float* wide_scr = reinterpret_cast<float*>(stat_scr);  // (the wide store's 4 KiB transpose scratch, same per-wave region)
     // 128-column groups of four column tiles = the statistics groups of the other tile shapes
     if constexpr (NT == 8) {
-        conv_store_tile<1, 4, EPI_ROWS, false>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][0]), a.w_unscale, b, ct * BM + wave * 32,
-                                               t0, r, h, ncols, Lout, tile_x * 2, stat_scr);
-        conv_store_tile<1, 4, EPI_ROWS, false>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][4]), a.w_unscale, b, ct * BM + wave * 32,
-                                               t0 + 128, r, h, ncols, Lout, tile_x * 2 + 1, stat_scr);
+        conv_store_group<EPI_ROWS>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][0]), a.w_unscale, b, ct * BM + wave * 32, t0, r, h,
+                                   ncols, Lout, tile_x * 2, stat_scr, wide_scr);
+        conv_store_group<EPI_ROWS>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][4]), a.w_unscale, b, ct * BM + wave * 32, t0 + 128, r,
+                                   h, ncols, Lout, tile_x * 2 + 1, stat_scr, wide_scr);
     } else {
-        conv_store_tile<1, 4, EPI_ROWS, false>(a, acc, a.w_unscale, b, ct * BM + wave * 32, t0, r, h, ncols, Lout, tile_x, stat_scr);
+        conv_store_group<EPI_ROWS>(a, acc, a.w_unscale, b, ct * BM + wave * 32, t0, r, h, ncols, Lout, tile_x, stat_scr, wide_scr);
     }
 }
 
+// The launchers below exist twice: this translation unit instantiates the f16x3 kernels (P1 = false); conv_f16x3_da_p1.hip
+// defines KX_DA_P1 and includes this file for the reduced-precision ones, so that the two sets compile side by side.
+#ifdef KX_DA_P1
+constexpr bool DA_P1 = true;
+#else
+constexpr bool DA_P1 = false;
+#endif
+
 template <int ACT, int KT, int NTT>
 static void launch_da_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
-    auto kern = conv1d_f16x3_da_kernel<ACT, KT, NTT>;
+    auto kern = conv1d_f16x3_da_kernel<ACT, KT, NTT, DA_P1>;
     constexpr int BN = 32 * NTT;
     // two input buffers (48 / 32 KiB), and never less than the statistics scratch of the epilogue (4 waves x 8.25 KiB)
     constexpr size_t lds_x = 16 * (size_t)2 * 4 * (BN + 128), lds_scr = 4 * 32 * 33 * sizeof(float2);
@@ -556,7 +578,7 @@ static void launch_da_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s
 
 template <int NTT>
 static void launch_da_ntt(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
-#ifdef KX_DA_AUDIT  // (tests/test_asm_audit_cpu.py compiles just these two instantiations to assembly)
+#ifdef KX_DA_AUDIT  // (tests/test_asm_audit_cpu.py: the early return keeps the build short; every instantiation is still emitted)
     if (a.act == ACT_SNAKE) launch_da_inst<ACT_SNAKE, 11, 8>(a, B, max_cols, s);
     else launch_da_inst<ACT_LEAKY, 0, 4>(a, B, max_cols, s);
     return;
@@ -575,6 +597,17 @@ static void launch_da_ntt(const ConvArgs& a, int B, int max_cols, hipStream_t s)
         launch_da_inst<ACT_NONE, 0, NTT>(a, B, max_cols, s);
 }
 
+#ifdef KX_DA_P1
+// bn: 256 or 128, as launch_conv1d_f16x3_da (which forwards here when a.prec1 is set)
+void launch_conv1d_f16x3_da_p1(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn) {
+    if (bn == 256)
+        launch_da_ntt<8>(a, B, max_cols, s);
+    else
+        launch_da_ntt<4>(a, B, max_cols, s);
+}
+#else
+void launch_conv1d_f16x3_da_p1(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn);  // conv_f16x3_da_p1.hip
+
 // bn: 256 (chip-filling launches) or 128 (small grids); the statistics slots are 128 columns wide either way
 void launch_conv1d_f16x3_da(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn) {
     KX_REQUIRE(conv16_da_eligible(128, a.K, a.dil, a.stride, a.merge_T > 0), "conv1d f16x3 da: launch not eligible");
@@ -582,9 +615,13 @@ void launch_conv1d_f16x3_da(const ConvArgs& a, int B, int max_cols, hipStream_t 
     KX_REQUIRE(a.epi != EPI_GELU_NEW, "conv1d f16x3 da: no gelu epilogue");
     KX_REQUIRE(bn == 256 || bn == 128, "conv1d f16x3 da: tile of 256 or 128 columns");
     if (max_cols <= 0) return;
+    if (a.prec1) {
+        launch_conv1d_f16x3_da_p1(a, B, max_cols, s, bn);
+        return;
+    }
     static const int dephase = getenv("KX_DEPHASE") ? atoi(getenv("KX_DEPHASE")) : 0;  // permille of a tile's estimated time
     static const int dephase_mode = getenv("KX_DEPHASE_MODE") ? atoi(getenv("KX_DEPHASE_MODE")) : 1;
-    if (dephase > 0 && bn == 256) {
+    if (dephase > 0 && bn == 256) {  // (diagnostic, profiles/r03_lanes_dephase.txt: no effect)
         ConvArgs d = a;
         const long grid_n = (long)((max_cols + 255) / 256) * ((a.Cout + 127) / 128) * B;
         // a tile: n_chunks x K x 8 column tiles x 3 MFMAs of 32 cycles, two waves per SIMD, ~80 % pipe use; + the epilogue
@@ -599,5 +636,6 @@ void launch_conv1d_f16x3_da(const ConvArgs& a, int B, int max_cols, hipStream_t 
     else
         launch_da_ntt<4>(a, B, max_cols, s);
 }
+#endif
 
 }  // namespace kx

@@ -93,6 +93,7 @@ struct ConvArgs {
     int xcd_swizzle;               // one-role f16x3 kernel: contiguous column tiles per XCD (1 unless KX_XCD_SWIZZLE=0)
     int ws_force;                  // test hook: 1 = the LDS-DMA kernel forms only (no direct-A kernel), 2 = the direct-A kernel whatever the grid
     unsigned long long* stamps;  // diagnostic build only: per-workgroup {t0,t1,t2,t3,hw_id,xcc_id,0,0}
+    int prec1;  // direct-A conv: the reduced-precision form (one f16 MFMA per product; KOKOROX_CONV=f16, opt-in)
     int dephase_cycles, dephase_mode;  // direct-A conv: start delay of half of the first round of workgroups (0 = off)
     int dbg;  // timing ablations (env KX_DBG): 1 skip input staging, 2 skip weight copies, 4 skip MFMA, 8 skip epilogue
 };
@@ -116,7 +117,7 @@ void launch_pack_convT(const float* w, float* dst, int Cin, int Cout, int s, int
 size_t packed_conv_floats(int rows, int Cin, int K, int BM);
 
 // f16x3 split path
-enum ConvMode { CONV_F32 = 0, CONV_F16X3 = 1, CONV_F16X3_LDS = 2, CONV_F16X3_DA = 3 };  // (2, 3: test hook only: f16x3 kept on the LDS-DMA kernel forms of conv_f16x3.hip / forced through conv_f16x3_da.hip)
+enum ConvMode { CONV_F32 = 0, CONV_F16X3 = 1, CONV_F16X3_LDS = 2, CONV_F16X3_DA = 3, CONV_F16 = 4 };  // (2, 3: test hook only: f16x3 kept on the LDS-DMA kernel forms of conv_f16x3.hip / forced through conv_f16x3_da.hip)
 void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStream_t s);
 void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int stride, int* bn, int* wn,
                       int ws_force = 0);  // (conv_f16x3.hip)

@@ -221,6 +221,7 @@ class Model {
     unsigned long long* d_xchg_[2] = {nullptr, nullptr};
     size_t xchg_cap_ = 0;
     unsigned xchg_epoch_[2] = {0, 0};  // launches on each exchange buffer since it was last cleared (16-bit tag epoch)
+    bool p1_region_ = false;           // inside the part of the forward whose direct-A convs may run reduced precision
     bool lstm_pair_ok_ = true;         // false once a hand-off timed out: the one-CU kernel from then on
     std::vector<long> h_off_;          // host staging that asynchronous copies read / write: outlives the calling frame
     unsigned h_bad_id_ = 0;

@@ -14,7 +14,8 @@ static constexpr float RSQRT2 = 0.70710678118654752f;
 static inline int up4(int x) { return (x + 31) & ~31; }
 
 Model::Model(int dev) : device(dev) {
-    if (const char* e = getenv("KOKOROX_CONV")) conv_mode = (strcmp(e, "f32") == 0) ? CONV_F32 : CONV_F16X3;
+    if (const char* e = getenv("KOKOROX_CONV"))
+        conv_mode = (strcmp(e, "f32") == 0) ? CONV_F32 : (strcmp(e, "f16") == 0 ? CONV_F16 : CONV_F16X3);
     if (const char* e = getenv("KOKOROX_STFT")) stft_variant = (strcmp(e, "torch") == 0) ? STFT_TORCH : STFT_ONNX;
     KX_HIP(hipSetDevice(device));
     KX_HIP(hipStreamCreate(&stream_));
@@ -481,7 +482,11 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     a.up_off = o.up_off;
     a.up_reflect = o.up_reflect;
     a.up_cout = w.up_cout ? w.up_cout : 1;
-    const bool f16 = conv_mode == CONV_F16X3;
+    const bool f16 = conv_mode == CONV_F16X3 || conv_mode == CONV_F16;
+    // reduced-precision mode (opt-in): the decoder and generator convs that take the direct-A kernel run one f16 MFMA
+    // per product; everything upstream of the F0 / N curves (duration head, prosody predictor) and every kernel that is
+    // not the direct-A conv (harmonic source, STFT pair, k = 1 GEMMs, conv_post) stays f32-class (hard part 3)
+    a.prec1 = (conv_mode == CONV_F16 && p1_region_) ? 1 : 0;
     a.w16 = w.w16;
     a.n_chunks16 = w.n_chunks16;
     static const int xcd_swz = getenv("KX_XCD_SWIZZLE") ? atoi(getenv("KX_XCD_SWIZZLE")) : 1;
@@ -498,7 +503,7 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     if (fuse_stats && o.stat_part && o.store == ST_NORMAL && !o.accum) {
         const int max_c = out.Lmax;
         int bn, wn;
-        if (conv_mode == CONV_F16X3) {
+        if (f16) {
             conv16_pick_tile(w.BM, max_c, B_, w.rows, w.K, o.dil, o.stride, &bn, &wn);
         } else {
             bn = conv_bn(w.BM);
@@ -872,6 +877,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     taps_on_ = (flags & 2u) != 0;
     taps_.clear();
     parts_.clear();
+    p1_region_ = false;
     lane_ev_used_ = 0;
     // Measured (profiles/r03_lanes_dephase.txt): at batch 1 the side-by-side chains take 10 % off the step (small grids
     // leave CUs idle: 13.8 -> 12.3 ms); at batch 64 every launch fills the chip and they change nothing (125.1 vs 125.1 ms)
@@ -1102,6 +1108,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
         T ns[2];
         hipEvent_t ev_ns[2] = {nullptr, nullptr};
         size_t part_n[2];
+        p1_region_ = true;  // (from here on: generator and decoder convs)
         {
             LaneScope on_lane(*this, 3);
             const long hs_ld = (long)600 * Fmax;
@@ -1221,6 +1228,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
             o.act = ACT_LEAKY; o.slope = 0.01f; o.pad = 3;
             conv(convs_.at(G + "conv_post"), x, cp, o);
         }
+        p1_region_ = false;
         tap("gen.conv_post", cp);
         float* spec = A.f((size_t)B * 22 * F120p);
         if (!dry_) launch_istft_head(cp.p, cp.bs, cp.ld, spec, d_audio, audio_ld, dF_, B, Fmax, stft_variant, stream_);

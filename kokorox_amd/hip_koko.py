@@ -314,7 +314,7 @@ class HipKoko:
         self._check(self._lib.kx_set_pinned_durations(self._h, _ptr(p), p.shape[0]))
 
     def set_conv_mode(self, mode: int):
-        """0 = f32 MFMA, 1 = f16x3 split MFMA (default)."""
+        """0 = f32 MFMA, 1 = f16x3 split MFMA (default), 4 = f16 single product (opt-in reduced precision)."""
         self._check(self._lib.kx_set_conv_mode(self._h, mode))
 
     def get_conv_mode(self) -> int:

@@ -49,8 +49,11 @@ def _regs(tok):
 
 
 def _audit_no_touch_before_wait(lines):
-    """Between an asm `global_load_dwordx4 vDST` and the next hand-written wait no other instruction may name vDST."""
-    pending, in_asm, bad = set(), False, []
+    """No instruction outside the hand-written asm may name the destination registers of an asm `global_load_dwordx4`
+    while that load can still be in flight.  Vector-memory operations of a wave complete in order, so a load with k younger
+    vector-memory operations behind it has landed at the first `s_waitcnt vmcnt(N)` with N <= k (text order; the branches
+    of the wait ladder all precede the use); waits that name only lgkmcnt retire nothing."""
+    pending, in_asm, bad, vm = [], False, [], 0
     for ln in lines:
         s = ln.strip()
         if s.startswith(";;#ASMSTART"):
@@ -62,30 +65,43 @@ def _audit_no_touch_before_wait(lines):
         if not s or s.startswith(";") or s.startswith("."):
             continue
         toks = re.findall(r"v\[\d+:\d+\]|v\d+\b", s)
+        if s.startswith("s_waitcnt"):
+            m = re.search(r"vmcnt\((\d+)\)", s)
+            if m:
+                n = int(m.group(1))
+                pending = [(regs, at) for regs, at in pending if n > vm - at]
+            continue
+        if re.match(r"(global|buffer|flat|scratch)_(load|store|atomic)", s):
+            vm += 1
+            if in_asm and s.startswith("global_load_dwordx4") and toks:
+                pending.append((_regs(toks[0]), vm))
+                continue
         if in_asm:
-            if s.startswith("global_load_dwordx4") and toks:
-                pending |= _regs(toks[0])
-            elif s.startswith("s_waitcnt"):
-                pending = set()
             continue
         used = set().union(*[_regs(t) for t in toks]) if toks else set()
-        if used & pending:
+        if any(used & regs for regs, _ in pending):
             bad.append(s)
     return bad
 
 
 def _prefetch_batches(lines):
-    """Sizes of the runs of scalar-dword vector loads that follow an s_barrier (the input prefetch of a chunk boundary)."""
+    """Sizes of the runs of scalar-dword vector loads that follow an s_barrier of the MAIN LOOP (the input prefetch of a
+    chunk boundary).  A run ends at the next MFMA or the next barrier, whichever comes first in the text: the compiler may
+    rotate the loop and place the latch (barrier + prefetch) ahead of the loop body, right behind the prologue's own
+    barrier + prefetch.  The epilogue's barrier is told apart by the buffer_* accesses that follow it (the main loop has
+    none)."""
     sizes, i = [], 0
     while i < len(lines):
         if lines[i].strip() == "s_barrier":
-            n, j = 0, i + 1
-            while j < len(lines) and j < i + 2000 and "v_mfma" not in lines[j]:
+            n, j, epilogue = 0, i + 1, False
+            while j < len(lines) and j < i + 4000 and "v_mfma" not in lines[j] and lines[j].strip() != "s_barrier":
                 if re.match(r"\s*global_load_dword\s", lines[j]):
                     n += 1
+                if re.match(r"\s*buffer_(load|store)", lines[j]):
+                    epilogue = True
+                    break
                 j += 1
-            # (only barriers of the main loop: MFMAs follow; the epilogue's barrier is followed by its own loads)
-            if n >= 8 and j < len(lines) and "v_mfma" in lines[j]:
+            if n >= 8 and not epilogue:
                 sizes.append(n)
             i = j
         else:
@@ -94,16 +110,20 @@ def _prefetch_batches(lines):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
-def test_direct_a_conv_assembly(tmp_path):
-    ks = _kernels(_asm("conv_f16x3_da.hip", tmp_path, "-DKX_DA_AUDIT"))
+@pytest.mark.parametrize("src", ["conv_f16x3_da.hip", "conv_f16x3_da_p1.hip"])  # f16x3 and reduced-precision instantiations
+def test_direct_a_conv_assembly(tmp_path, src):
+    ks = _kernels(_asm(src, tmp_path, "-DKX_DA_AUDIT"))
     assert ks, "no kernel found"
+    assert len(ks) == 14, sorted(ks)  # every instantiation launch_da_ntt can select, both tile widths
     for name, lines in ks.items():
         assert not any("scratch_" in ln for ln in lines), f"{name} spills"
         bad = _audit_no_touch_before_wait(lines)
         assert not bad, f"{name}: ring registers touched before their wait: {bad[:3]}"
-        m = re.search(r"da_kernelILi(\d+)ELi(\d+)ELi(\d+)E", name)
+        m = re.search(r"da_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb[01]E", name)
         act, kt, ntt = (int(x) for x in m.groups())
-        hu = (32 * ntt + 128) // 128 * 8
+        # elements per lane and chunk: BN + 128 staged columns in the run-time form, BN + 64 (last block split over the four
+        # waves by channel) in the unrolled forms
+        hu = 8 * (ntt // 4) + 4 if kt > 0 else (32 * ntt + 128) // 128 * 8
         want = hu + 3 + (1 if act == 2 else 0)  # raw_ops with the three InstanceNorm parameter loads present
         sizes = _prefetch_batches(lines)
         assert sizes and all(sz == want for sz in sizes), f"{name}: input prefetch is {sizes} loads, raw_ops assumes {want}"

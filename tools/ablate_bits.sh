@@ -3,7 +3,7 @@
 # (bits: 1 no input staging, 2 no weight copies, 4 no MFMAs, 8 no epilogue, 32 stores over row 0, 64 residual from row 0)
 tag=$1; shift
 for dbg in "$@"; do
-  KX_DBG=$dbg timeout -k 10 200 python bench.py --steps 3 --warmup 1 --cpu-utts 0 --free-run 0 --pcie 0 --serve 0 \
+  KX_DBG=$dbg timeout -k 10 200 python bench.py --steps 3 --warmup 1 --cpu-utts 0 --free-run 0 --pcie 0 --serve 0 --reduced 0 \
       --detail gpurun_out/${tag}_dbg$dbg.txt > gpurun_out/${tag}_dbg$dbg.json 2> gpurun_out/${tag}_dbg$dbg.err || exit 1
   python - <<PY
 import json
