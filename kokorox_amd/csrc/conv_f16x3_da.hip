@@ -62,8 +62,16 @@ template <int ACT, int KT, int NTT, bool P1>
 __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(const ConvArgs a) {
     // NTT = 8: the 128 x 256 tile of chip-filling launches; NTT = 4: 128 x 128 for small grids (batch 1), three workgroups per CU
     constexpr int BM = 128, NT = NTT, BN = 32 * NT;
-    constexpr int HU = (BN + 128) / 128 * 8;  // elements per lane and chunk = half-units of the interleaved transform
-    constexpr int XWp = BN + 128;           // window pitch of one image row (columns)
+    // Staged window.  Run-time tap count: BN + 128 columns = NJF 64-column blocks per wave pair, 8 channels each.
+    // Compile-time tap counts (the resblock convs, (KT - 1) dil <= 64 checked at launch): BN + 64 columns -- the last block
+    // is SPLIT over all four waves by channel (4 of the 16 channels each), so that a lane transforms 8 NJF + 4 elements
+    // per chunk instead of 8 (NJF + 1): 20 instead of 24 on the 256-column tile (12 / 16 on the 128-column one), and a
+    // sixth less input is fetched (round 2 staged 384 columns for 256 + 10 .. 50 needed).
+    constexpr bool W64 = KT > 0;
+    constexpr int NJF = W64 ? BN / 128 : (BN + 128) / 128;  // whole blocks per lane
+    constexpr int NJ = NJF + (W64 ? 1 : 0);                 // + the split block
+    constexpr int HU = 8 * NJF + (W64 ? 4 : 0);             // elements per lane and chunk = half-units of the interleaved transform
+    constexpr int XWp = W64 ? BN + 64 : BN + 128;           // window pitch of one image row (columns)
     constexpr int XBUF = 4 * XWp;           // uint4 per input buffer: [hi|lo][octet][XWp]
     constexpr int tap_units = 4 * BM;       // uint4 per (chunk, tap) of the packed weights: [hi|lo][k-half][BM]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
@@ -134,15 +142,16 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
 
     // ---- input chunk staging: the scheme of conv1d_f16x3_kernel (wave w: channel octet w & 1, every other 64-column
     // block of the window; raw values and per-channel parameters of the NEXT chunk prefetched across the MFMA loop)
-    constexpr int NJ = XWp / 128;
     const int g = wave & 1, jb = wave >> 1;
-    float raw[NJ][8];
+    float raw[NJ][8];  // (split block: elements 0..3 = channels 4 jb .. 4 jb + 3 of the wave's octet)
     float praw[4];
     int xoff[NJ];
     unsigned okmask = 0;
+    // first column of the wave's block j: whole blocks alternate between the wave pairs, the split block is the window's last
+    auto blk_col = [&](int j) __attribute__((always_inline)) { return (W64 && j == NJF) ? 64 * 2 * NJF : 64 * (jb + 2 * j); };
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int p = p0 + lane + 64 * (jb + 2 * j);
+        const int p = p0 + lane + blk_col(j);
         okmask |= (p >= 0 && p < Lin) ? (1u << j) : 0u;
         int pi = up2 ? (p >> 1) : p;
         pi = pi < 0 ? 0 : (pi >= Lsrc ? Lsrc - 1 : pi);
@@ -172,7 +181,14 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
             const int ci = ch * CK16 + g * 8 + c;
             const float* row = xb + (long)(ci < cmax_in ? ci : cmax_in) * a.x_ld;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) raw[j][c] = row[xoff[j]];
+            for (int j = 0; j < NJF; ++j) raw[j][c] = row[xoff[j]];
+        }
+        if constexpr (W64) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ci = ch * CK16 + g * 8 + jb * 4 + c;
+                raw[NJF][c] = (xb + (long)(ci < cmax_in ? ci : cmax_in) * a.x_ld)[xoff[NJF]];
+            }
         }
     };
     struct Oct { float m[8], s[8], h[8], al[8], ial[8]; };
@@ -204,14 +220,40 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         Xb[(0 * 2 + g) * XWp + u] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
         if constexpr (!P1) Xb[(1 * 2 + g) * XWp + u] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
     };
+    // the split block's four elements (channels 4 jb + c of the octet; parameters by run-time lane index: jb is wave-uniform)
+    auto emit4 = [&](uint4* Xb, int ch, int u, const float (&x8)[8], const float (&pv)[4], bool pok) __attribute__((always_inline)) {
+        const float al_or_rcp = (lane & 8) ? 1.0f / pv[3] : pv[3];
+        const float keep = pok ? a.x_prescale : 0.f;
+        unsigned hp[2], lp[2];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            float y2[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c = 2 * c2 + q, cl = jb * 4 + c;
+                const float m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv[0]), cl));
+                const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv[1]), cl));
+                const float sh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv[2]), cl));
+                const float al = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al_or_rcp), cl));
+                const float ial = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al_or_rcp), cl + 8));
+                const float y = in_act<ACT>(__builtin_fmaf(x8[c] - m, sc, sh), a.slope, al, ial);
+                y2[q] = y * ((ch * CK16 + g * 8 + cl <= cmax_in) ? keep : 0.f);
+            }
+            split_pair(y2[0], y2[1], hp[c2], lp[c2]);
+        }
+        uint2* Xw2 = reinterpret_cast<uint2*>(Xb);
+        Xw2[((0 * 2 + g) * XWp + u) * 2 + jb] = make_uint2(hp[0], hp[1]);
+        if constexpr (!P1) Xw2[((1 * 2 + g) * XWp + u) * 2 + jb] = make_uint2(lp[0], lp[1]);
+    };
     auto stage_from_raw = [&](uint4* Xb, int ch) __attribute__((always_inline)) {
         Oct o;
         unpack_params(praw, o);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) emit8(Xb, ch, lane + 64 * (jb + 2 * j), raw[j], o, ((okmask >> j) & 1u) != 0u);
+        for (int j = 0; j < NJF; ++j) emit8(Xb, ch, lane + blk_col(j), raw[j], o, ((okmask >> j) & 1u) != 0u);
+        if constexpr (W64) emit4(Xb, ch, lane + blk_col(NJF), raw[NJF], praw, ((okmask >> NJF) & 1u) != 0u);
     };
 
-    // ---- the same transform cut into 12 units of one column block x one channel pair (2 of the lane's 24 elements),
+    // ---- the same transform cut into HU / 2 units of one column block x one channel pair (2 of the lane's HU elements),
     // each in two halves of one element (~25 vector instructions; the second half packs the pair and writes its two
     // dwords of the image), to be issued BETWEEN the MFMAs of 24 consecutive column tiles = three steps.
     // Measured (profiles/r02_da_ablations.txt): the transform of a chunk, done in one piece at the chunk's end, costs
@@ -225,12 +267,15 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     // of emit8 / in_act / sin_sq, operation for operation (results must not depend on where a chunk was transformed).
     // U: unit (column block U / 4, channel pair U % 4), half: element of the pair; both constants once inlined.
     auto xform_a = [&](const int U, const int half, int ch) __attribute__((always_inline)) {
-        const int j = U / 4, cq = 2 * (U % 4) + half;
+        // units 0 .. 4 NJF - 1: whole blocks (block U / 4, channel pair U % 4); the last two: the split block's two pairs
+        const bool split = W64 && U >= 4 * NJF;
+        const int j = split ? NJF : U / 4, cr = split ? 2 * (U - 4 * NJF) + half : 2 * (U % 4) + half;  // element in raw[j]
+        const int cq = split ? jb * 4 + cr : cr;                                                         // channel of the octet
         if (U == 0 && half == 0) al_rcp_x = (lane & 8) ? 1.0f / praw[3] : praw[3];
         const float m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, praw[0]), cq));
         const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, praw[1]), cq));
         const float sh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, praw[2]), cq));
-        xt_ = __builtin_fmaf(raw[j][cq] - m, sc, sh);
+        xt_ = __builtin_fmaf(raw[j][cr] - m, sc, sh);
         if (ACT == ACT_SNAKE) {
             const float al = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al_rcp_x), cq));
             const float t = al * xt_;
@@ -252,7 +297,10 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         }
     };
     auto xform_c = [&](const int U, const int half, uint4* Xb, int ch) __attribute__((always_inline)) {
-        const int j = U / 4, c2 = U % 4, cq = 2 * c2 + half;
+        const bool split = W64 && U >= 4 * NJF;
+        const int j = split ? NJF : U / 4;
+        const int c2 = split ? jb * 2 + (U - 4 * NJF) : U % 4;  // channel pair of the octet = dword of the 16-byte slot
+        const int cq = 2 * c2 + half;
         float y;
         if (ACT == ACT_SNAKE) {
             const float ial = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al_rcp_x), cq + 8));
@@ -267,7 +315,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         } else {
             unsigned hp, lp;
             split_pair(y_carry, y, hp, lp);
-            const int u = lane + 64 * (jb + 2 * j);
+            const int u = lane + blk_col(j);
             unsigned* Xw = reinterpret_cast<unsigned*>(Xb);
             Xw[((0 * 2 + g) * XWp + u) * 4 + c2] = hp;
             if constexpr (!P1) Xw[((1 * 2 + g) * XWp + u) * 4 + c2] = lp;
@@ -585,13 +633,15 @@ static void launch_da_ntt(const ConvArgs& a, int B, int max_cols, hipStream_t s)
 #endif
     // the resblock tap counts get the unrolled form with the transform between the MFMAs (KX_DA_STATIC=0: run-time form)
     static const int st = getenv("KX_DA_STATIC") ? atoi(getenv("KX_DA_STATIC")) : 1;
+    // (the unrolled forms stage a window of BN + 64 columns: (K - 1) dil <= 64, true of every resblock conv of the graph)
+    const bool w64 = (a.K - 1) * a.dil <= 64;
     if (a.act == ACT_SNAKE) {
-        if (st && a.K == 11) launch_da_inst<ACT_SNAKE, 11, NTT>(a, B, max_cols, s);
-        else if (st && a.K == 7) launch_da_inst<ACT_SNAKE, 7, NTT>(a, B, max_cols, s);
-        else if (st && a.K == 3) launch_da_inst<ACT_SNAKE, 3, NTT>(a, B, max_cols, s);
+        if (st && w64 && a.K == 11) launch_da_inst<ACT_SNAKE, 11, NTT>(a, B, max_cols, s);
+        else if (st && w64 && a.K == 7) launch_da_inst<ACT_SNAKE, 7, NTT>(a, B, max_cols, s);
+        else if (st && w64 && a.K == 3) launch_da_inst<ACT_SNAKE, 3, NTT>(a, B, max_cols, s);
         else launch_da_inst<ACT_SNAKE, 0, NTT>(a, B, max_cols, s);
     } else if (a.act == ACT_LEAKY) {
-        if (st && a.K == 3) launch_da_inst<ACT_LEAKY, 3, NTT>(a, B, max_cols, s);
+        if (st && w64 && a.K == 3) launch_da_inst<ACT_LEAKY, 3, NTT>(a, B, max_cols, s);
         else launch_da_inst<ACT_LEAKY, 0, NTT>(a, B, max_cols, s);
     } else
         launch_da_inst<ACT_NONE, 0, NTT>(a, B, max_cols, s);
