@@ -369,6 +369,13 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     // Three-deep A ring with STATIC slots: step s uses slot s % 3 and refills it for step s + 3 as soon as its MFMAs are
     // issued, so a fragment is requested two whole steps before its use and nothing ever moves between registers.  The
     // (chunk, tap) walk is flattened and unrolled by three for that.
+#ifdef KX_DA_STAMPS  // diagnostic build only (tools/stamp_timeline.py): per-workgroup phase stamps; nothing reads them back
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, cyc0 = 0;
+    if (a.stamps) {
+        st0 = __builtin_amdgcn_s_memrealtime();
+        cyc0 = __builtin_readcyclecounter();
+    }
+#endif
     u32x4 ah0, al0 = {0, 0, 0, 0}, ah1, al1 = {0, 0, 0, 0}, ah2, al2 = {0, 0, 0, 0};
     load_A(0, ah0, al0);
     load_A(1, ah1, al1);
@@ -383,6 +390,9 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     stage_from_raw(Xs, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (once: the ages below start from an empty queue)
     __syncthreads();
+#ifdef KX_DA_STAMPS
+    if (a.stamps) st1 = __builtin_amdgcn_s_memrealtime();
+#endif
     int age0 = 0, age1 = 0, age2 = 0;
     if (n_chunks > 1 && !(a.dbg & 1)) {
         load_raw(1);
@@ -587,6 +597,9 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (belt and braces: no hand-counted load is in flight past this point)
+#ifdef KX_DA_STAMPS
+    if (a.stamps) st2 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (a.dbg & 8) return;
     // the statistics scratch of the epilogue lives in the input buffers: everybody must be done reading them
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -601,6 +614,19 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     } else {
         conv_store_group<EPI_ROWS>(a, acc, a.w_unscale, b, ct * BM + wave * 32, t0, r, h, ncols, Lout, tile_x, stat_scr, wide_scr);
     }
+#ifdef KX_DA_STAMPS
+    if (a.stamps && tid == 0) {
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        unsigned long long* o = a.stamps + (unsigned long long)lin * 8;
+        o[0] = st0; o[1] = st1; o[2] = st2;
+        __builtin_amdgcn_s_waitcnt(0);
+        o[3] = __builtin_amdgcn_s_memrealtime();
+        o[4] = __builtin_amdgcn_s_getreg(63492);  // HW_REG_HW_ID
+        o[5] = __builtin_readcyclecounter() - cyc0;
+        o[6] = __builtin_amdgcn_s_getreg(63508);  // HW_REG_XCC_ID
+        o[7] = 0;
+    }
+#endif
 }
 
 // The launchers below exist twice: this translation unit instantiates the f16x3 kernels (P1 = false); conv_f16x3_da_p1.hip
