@@ -49,7 +49,7 @@ def _regs(tok):
 
 
 def _audit_no_touch_before_wait(lines):
-    """No instruction outside the hand-written asm may name the destination registers of an asm `global_load_dwordx4`
+    """No instruction outside the hand-written asm may name the destination registers of an asm `global_load_dword[x4]`
     while that load can still be in flight.  Vector-memory operations of a wave complete in order, so a load with k younger
     vector-memory operations behind it has landed at the first `s_waitcnt vmcnt(N)` with N <= k (text order; the branches
     of the wait ladder all precede the use); waits that name only lgkmcnt retire nothing."""
@@ -73,7 +73,7 @@ def _audit_no_touch_before_wait(lines):
             continue
         if re.match(r"(global|buffer|flat|scratch)_(load|store|atomic)", s):
             vm += 1
-            if in_asm and s.startswith("global_load_dwordx4") and toks:
+            if in_asm and s.startswith("global_load_dword") and toks:  # ring (dwordx4) and input prefetch (dword) loads
                 pending.append((_regs(toks[0]), vm))
                 continue
         if in_asm:
