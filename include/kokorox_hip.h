@@ -144,7 +144,8 @@ int kx_get_stft_variant(kx_model* m);
 
 /* Streams ("lanes") of the back half: 1 = every launch on the model's one stream; 4 = the harmonic-source / noise path
  * and the three resblock chains of each generator stage are issued on streams of their own and meet through events;
- * 0 (default) = 4 for batches of up to 16 utterances, where launches leave CUs idle (batch 1: 13.8 -> 12.3 ms), else 1.
+ * 0 (default) = 4 for batches of up to 32 utterances, where launches leave CUs idle (batch 1: 14.1 -> 11.9 ms), else 1.
+ * Also side by side in that mode: the F0 and N predictor branches, and the 1x1 shortcut conv of every AdainResBlk1d.
  * Results are bit-identical for every value: only the last conv of a chain touches the shared running sum, in a fixed
  * order.  Env KX_LANES at create. */
 int kx_set_lanes(kx_model* m, int n_lanes);

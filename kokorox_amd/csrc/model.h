@@ -179,7 +179,7 @@ class Model {
         float *nmean = nullptr, *nscale = nullptr, *nshift = nullptr;
     };
     Lane lanes_[N_LANES];
-    int lanes_cfg_ = 0;  // 0 = by batch size (4 up to 16 utterances, else 1), 1..4 = fixed (KX_LANES, kx_set_lanes)
+    int lanes_cfg_ = 0;  // 0 = by batch size (4 up to 32 utterances, else 1), 1..4 = fixed (KX_LANES, kx_set_lanes)
     int n_lanes_ = 1;    // lanes of the running call
     std::vector<hipEvent_t> lane_ev_;
     size_t lane_ev_used_ = 0;

@@ -661,6 +661,24 @@ void Model::adain_resblk(const std::string& name, const T& x, const T& out, bool
     T t1 = out;
     t1.p = ws_a;
     t1.bs = (long)out.C * out.ld;
+    // the 1x1 shortcut depends on x only: it is issued first, on a side lane, and joins before conv2 reads it
+    T sc = out;
+    const T* res = &x;
+    hipEvent_t ev_sc = nullptr;
+    if (convs_.count(name + ".conv1x1")) {
+        sc.p = ws_b;
+        sc.bs = (long)out.C * out.ld;
+        ConvOpts osc;
+        osc.in_up2 = upsample ? 1 : 0;
+        {
+            LaneScope side(*this, 2);
+            conv(convs_.at(name + ".conv1x1"), x, sc, osc);
+            ev_sc = record_here();
+        }
+        res = &sc;
+    } else {
+        KX_REQUIRE(!upsample && x.C == out.C, "internal: identity shortcut needs equal shapes");
+    }
     stats(x, name + ".norm1");
     if (!upsample) {
         ConvOpts o;
@@ -680,23 +698,12 @@ void Model::adain_resblk(const std::string& name, const T& x, const T& out, bool
         conv(c1, p, t1, o);
     }
     stats(t1, name + ".norm2");
-    T sc = out;
-    const T* res = &x;
-    if (convs_.count(name + ".conv1x1")) {
-        sc.p = ws_b;
-        sc.bs = (long)out.C * out.ld;
-        ConvOpts o;
-        o.in_up2 = upsample ? 1 : 0;
-        conv(convs_.at(name + ".conv1x1"), x, sc, o);
-        res = &sc;
-    } else {
-        KX_REQUIRE(!upsample && x.C == out.C, "internal: identity shortcut needs equal shapes");
-    }
     ConvOpts o;
     o.nmean = nmean_; o.nscale = nscale_; o.nshift = nshift_;
     o.act = ACT_LEAKY; o.slope = 0.2f; o.pad = 1;
     o.resid = res;
     o.out_mul = RSQRT2;
+    wait_here(ev_sc);  // (the shortcut ran beside conv1)
     conv(c2, t1, out, o);
 }
 
@@ -879,10 +886,11 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     parts_.clear();
     p1_region_ = false;
     lane_ev_used_ = 0;
-    // Measured (profiles/r03_lanes_dephase.txt): at batch 1 the side-by-side chains take 10 % off the step (small grids
-    // leave CUs idle: 13.8 -> 12.3 ms); at batch 64 every launch fills the chip and they change nothing (125.1 vs 125.1 ms)
-    // while the per-launch event timings of the profile mode would overlap.  So: lanes for small batches only.
-    n_lanes_ = lanes_cfg_ ? lanes_cfg_ : (B <= 16 ? N_LANES : 1);
+    // Measured (profiles/r03_lanes_dephase.txt): side-by-side chains take 15 % off the batch-1 step (small grids leave CUs
+    // idle: 14.1 -> 11.9 ms), 14 % at batch 4, 6 % at batch 16; at batch 64 every launch fills the chip and they change
+    // nothing (125.1 vs 125.1 ms) while the per-launch event timings of the profile mode would overlap.  So: lanes for
+    // small batches only.
+    n_lanes_ = lanes_cfg_ ? lanes_cfg_ : (B <= 32 ? N_LANES : 1);
     hT_.assign(lens_host, lens_host + B);
     hF_.assign(B, 0);
     const int Tp = up4(Tmax);
@@ -1087,8 +1095,13 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
         lstm(lstms_.at("predictor.shared"), en, xsh, gxF);
         tap("pred.shared", xsh);
         T curves = F2(2);  // row 0 = F0 curve, row 1 = N curve, length 2F
-        for (int br = 0; br < 2; ++br) {
+        // The F0 and the N branch read xsh and are independent: N goes to lane 1, F0 stays here.  The raw InstanceNorm sums
+        // of xsh are computed once, before the fork (stats() caches them per tensor).
+        stats(xsh, "predictor.F0.0.norm1");
+        hipEvent_t ev_n = nullptr;
+        for (int br = 1; br >= 0; --br) {
             const std::string P = std::string("predictor.") + (br == 0 ? "F0" : "N");
+            LaneScope on_lane(*this, br);
             T y0 = F1(512);
             adain_resblk(P + ".0", xsh, y0, false, A.f((size_t)B * 512 * F1p), nullptr, nullptr);
             T y1 = F2(256);
@@ -1099,7 +1112,9 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
             T y2 = F2(256);
             adain_resblk(P + ".2", y1, y2, false, A.f((size_t)B * 256 * F2p), nullptr, nullptr);
             conv(convs_.at(P + "_proj"), y2, curves.rows(br, 1), ConvOpts{});
+            if (br == 1) ev_n = record_here();
         }
+        wait_here(ev_n);
         tap("pred.F0", curves.rows(0, 1));
         tap("pred.N", curves.rows(1, 1));
         // --- Generator, source side: harmonic source -> STFT -> noise_convs / noise_res of both stages.  It depends on the

@@ -328,7 +328,7 @@ class HipKoko:
         return int(self._lib.kx_get_stft_variant(self._h))
 
     def set_lanes(self, n: int):
-        """1 = one stream; 4 = the independent chains of the back half side by side; 0 (default) = 4 up to batch 16,
+        """1 = one stream; 4 = the independent chains of the back half side by side; 0 (default) = 4 up to batch 32,
         else 1.  Bit-identical results for every value."""
         self._check(self._lib.kx_set_lanes(self._h, n))
 

@@ -18,5 +18,5 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write
 cd $R
 python tools/summarize_rocprof.py gpurun_out/${TAG}_prof gpurun_out/${TAG}_prof_bench.json gpurun_out/${TAG}_kernel_stats_f16x3.txt > /dev/null
 head -12 gpurun_out/${TAG}_kernel_stats_f16x3.txt | cut -c1-150
-python tools/summarize_rocprof.py gpurun_out/${TAG}_prof_b1 gpurun_out/${TAG}_prof_b1_bench.json gpurun_out/${TAG}_kernel_stats_f16x3_batch1.txt > /dev/null
+python tools/summarize_rocprof.py gpurun_out/${TAG}_prof_b1 gpurun_out/${TAG}_prof_b1_bench.json gpurun_out/${TAG}_kernel_stats_f16x3_batch1.txt "python3 bench.py --batch 1 --steps 10 --warmup 2 --cpu-utts 0 --free-run 0 --pcie 0 --serve 0 --reduced 0" > /dev/null
 python tools/summarize_pmc.py gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write gpurun_out/${TAG}_pmc_conv_traffic_f16x3.json gpurun_out/${TAG}_pmc_fetch.log "conv1d_f16x3_kernel<128,|conv1d_f16x3_da_kernel<|conv1d_f16x3_dag_kernel<" f16x3

@@ -6,13 +6,13 @@ import os
 import sys
 
 
-def main(prof_dir, bench_json, out):
+def main(prof_dir, bench_json, out, cmd=""):
     stats = glob.glob(os.path.join(prof_dir, "*", "*_kernel_stats.csv"))[0]
     rows = list(csv.DictReader(open(stats)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     lines = [f"# rocprofv3 --kernel-trace --stats summary ({os.path.basename(prof_dir)})",
-             "# command: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py "
-             "--steps 3 --warmup 1 --cpu-utts 0 --free-run 0 --pcie 0",
+             "# command: rocprofv3 --kernel-trace --stats --output-format csv -- " + (cmd or "python3 bench.py --steps 3 --warmup 1 "
+                                                                                      "--cpu-utts 0 --free-run 0 --pcie 0 --serve 0 --reduced 0"),
              f"# total GPU kernel time {tot / 1e6:.2f} ms", "",
              f"{'kernel':88s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>7s}"]
     for r in rows:
@@ -41,4 +41,4 @@ def main(prof_dir, bench_json, out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "", sys.argv[3])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "", sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
