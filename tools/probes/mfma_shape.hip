@@ -1,0 +1,148 @@
+// Probe: f16 MFMA shape under the chip's power limit.  Same accumulator footprint per wave (32 rows x 256 columns of f32),
+// same FLOPs and the same matrix-pipe cycles per step, issued as v_mfma_f32_32x32x16_f16 (8 tiles x 3 per K = 16) or as
+// v_mfma_f32_16x16x32_f16 (32 blocks x 3 per K = 32); operands re-read from LDS by ds_read_b128 every step, as the direct-A
+// conv does for its B fragments, on random data.  Two workgroups of four waves per CU.  Optionally a streaming epilogue
+// (out = acc + resid, dword form) so that HBM traffic draws power beside the MFMAs as in the real kernel.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int SHAPE>
+__global__ __launch_bounds__(256, 2) void probe(const uint4* frag_src, int steps16, float* y, const float* resid, long ld, int do_e,
+                                                unsigned long long* clk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* lds = reinterpret_cast<uint4*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2048; i += 256) lds[i] = frag_src[(blockIdx.x * 2048 + i) & 0xfffff];  // 32 KiB of random halves
+    __syncthreads();
+    half8 a_hi = __builtin_bit_cast(half8, frag_src[tid]), a_lo = __builtin_bit_cast(half8, frag_src[tid + 256]);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_readcyclecounter();
+    float sink = 0.f;
+    if constexpr (SHAPE == 0) {
+        f32x16 acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        for (int s = 0; s < steps16; ++s) {
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                const half8 bh = __builtin_bit_cast(half8, lds[((s * 8 + n) * 2 * 64 + lane) & 2047]);
+                const half8 bl = __builtin_bit_cast(half8, lds[((s * 8 + n) * 2 * 64 + 64 + lane) & 2047]);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bh, acc[n], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sink += acc[j][e];
+        if (do_e) {
+            float* yb = y + (long)(blockIdx.x * 128 + wave * 32 + 4 * (lane >> 5)) * ld + (lane & 31);
+            const float* rb = resid + (long)(blockIdx.x * 128 + wave * 32 + 4 * (lane >> 5)) * ld + (lane & 31);
+#pragma unroll
+            for (int n = 0; n < 8; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const long o = (long)((e & 3) + 8 * (e >> 2)) * ld + 32 * n;
+                    yb[o] = acc[n][e] + rb[o];
+                }
+        }
+    } else {
+        f32x4 acc[2][16];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const half8 a2_hi = __builtin_bit_cast(half8, frag_src[tid + 512]), a2_lo = __builtin_bit_cast(half8, frag_src[tid + 768]);
+        for (int s = 0; s < steps16 / 2; ++s) {  // K = 32 per step: the work of two K = 16 steps
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const half8 bh = __builtin_bit_cast(half8, lds[((s * 16 + n) * 2 * 64 + lane) & 2047]);
+                const half8 bl = __builtin_bit_cast(half8, lds[((s * 16 + n) * 2 * 64 + 64 + lane) & 2047]);
+                acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, bh, acc[0][n], 0, 0, 0);
+                acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bl, acc[0][n], 0, 0, 0);
+                acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bh, acc[0][n], 0, 0, 0);
+                acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2_lo, bh, acc[1][n], 0, 0, 0);
+                acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2_hi, bl, acc[1][n], 0, 0, 0);
+                acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2_hi, bh, acc[1][n], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sink += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (do_e) {  // C/D of 16x16: column lane & 15, rows 4 (lane >> 4) + i
+            float* yb = y + (long)(blockIdx.x * 128 + wave * 32 + 4 * (lane >> 4)) * ld + (lane & 15);
+            const float* rb = resid + (long)(blockIdx.x * 128 + wave * 32 + 4 * (lane >> 4)) * ld + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int n = 0; n < 16; ++n)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const long o = (long)(16 * i + q) * ld + 16 * n;
+                        yb[o] = acc[i][n][q] + rb[o];
+                    }
+        }
+    }
+    if (tid == 0) {
+        clk[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime() - t0;
+        clk[blockIdx.x * 2 + 1] = __builtin_readcyclecounter() - c0;
+    }
+    if (sink == 123.456f) y[0] = sink;
+}
+
+int main(int argc, char** argv) {
+    const int steps16 = argc > 1 ? atoi(argv[1]) : 704;  // 8 chunks x 11 taps x 8 (so that one launch ~ one conv launch of work)
+    const int n_wg = 12672 / 8;                           // 8x the work per workgroup, an eighth of the workgroups: same FLOPs as a k = 11 launch
+    const long ld = 256;
+    uint4* frag;
+    float *y, *res;
+    unsigned long long* clk;
+    std::vector<unsigned short> h((1 << 20) * 8);
+    srand(1);
+    for (auto& v : h) {  // random f16 in about [-2, 2): sign, exponent 12..16, random mantissa
+        v = (unsigned short)(((rand() & 1) << 15) | ((12 + rand() % 5) << 10) | (rand() & 1023));
+    }
+    hipMalloc(&frag, h.size() * 2);
+    hipMemcpy(frag, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    hipMalloc(&y, (size_t)n_wg * 128 * ld * 4);
+    hipMalloc(&res, (size_t)n_wg * 128 * ld * 4);
+    hipMemset(res, 0, (size_t)n_wg * 128 * ld * 4);
+    hipMalloc(&clk, n_wg * 16);
+    for (int e = 0; e < 2; ++e)
+        for (int shape = 0; shape < 2; ++shape) {
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+            auto launch = [&]() {
+                if (shape == 0) hipLaunchKernelGGL(probe<0>, dim3(n_wg), dim3(256), 32768, 0, frag, steps16, y, res, ld, e, clk);
+                else hipLaunchKernelGGL(probe<1>, dim3(n_wg), dim3(256), 32768, 0, frag, steps16, y, res, ld, e, clk);
+            };
+            for (int i = 0; i < 20; ++i) launch();  // ~ 50 ms of load first: the clock settles
+            hipDeviceSynchronize();
+            hipEventRecord(e0);
+            for (int i = 0; i < 20; ++i) launch();
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            std::vector<unsigned long long> c(n_wg * 2);
+            hipMemcpy(c.data(), clk, n_wg * 16, hipMemcpyDeviceToHost);
+            double mhz = 0;
+            for (int i = 0; i < n_wg; ++i) mhz += (double)c[2 * i + 1] / ((double)c[2 * i] / 100.0);
+            const double flops = (double)n_wg * 4 * steps16 * 8 * 3 * (32.0 * 32 * 16 * 2);
+            printf("%s  %-12s %.3f ms per launch, %.0f TFLOP/s issued (%.0f algorithmic at 3 per product), shader clock %.0f MHz\n",
+                   e ? "M + stores" : "M only    ", shape ? "16x16x32" : "32x32x16", ms / 20, flops / (ms / 20 * 1e-3) / 1e12,
+                   flops / 3 / (ms / 20 * 1e-3) / 1e12, mhz / n_wg);
+        }
+    return 0;
+}
