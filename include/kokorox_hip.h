@@ -70,9 +70,10 @@ int kx_create_replicas(const char* weights_path, const int* device_ids, int n, k
 /* Replaces `Drop for OrtKoko` / TTSKoko::cleanup (kokorox/src/tts/koko.rs:1338-1375). */
 void kx_destroy(kx_model* m);
 
-/* Text of the last failure on this model ("" if none).  The returned pointer refers to a copy owned by the
- * calling thread: it stays valid until that thread calls kx_last_error again, whatever other threads do with
- * the model.  kx_last_error_copy writes the same text into a caller buffer (always NUL-terminated). */
+/* Text of the CALLING THREAD's last failed call on this model ("" if its last call succeeded or it never failed):
+ * several threads may share one model (calls are serialised inside), and neither another thread's success nor its
+ * failure touches what this thread reads.  The pointer stays valid until the calling thread's next call on any model.
+ * kx_last_error_copy writes the same text into a caller buffer (always NUL-terminated). */
 const char* kx_last_error(const kx_model* m);
 int kx_last_error_copy(const kx_model* m, char* buf, size_t buf_len);
 

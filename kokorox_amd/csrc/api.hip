@@ -19,22 +19,36 @@ static void set_err(char* err, size_t n, const std::string& msg) {
     }
 }
 
+// The message of a failed call belongs to the THREAD that made the call (several threads may share one model: the Rust
+// handle is Send + Sync): it is kept per thread, set by that thread's own failure and cleared by its own next success on
+// the same model, so another thread's calls can neither blank it nor replace it.
+static thread_local std::string tls_last_error;
+static thread_local const void* tls_last_error_model = nullptr;
+
+static void note_error(const kx_model* h, const std::string& msg) {
+    tls_last_error = msg;
+    tls_last_error_model = h;
+}
+
 template <class F>
 static int guarded(kx_model* h, F&& f) {
     if (!h || !h->m) return KX_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->m->mu);
     try {
         f(*h->m);
-        h->m->last_error.clear();
+        if (tls_last_error_model == h) {
+            tls_last_error.clear();
+            tls_last_error_model = nullptr;
+        }
         return KX_OK;
     } catch (const Error& e) {
-        h->m->last_error = e.what();
+        note_error(h, e.what());
         return e.code;
     } catch (const std::exception& e) {
-        h->m->last_error = e.what();
+        note_error(h, e.what());
         return KX_ERR_DEVICE;
     } catch (...) {
-        h->m->last_error = "unknown failure";
+        note_error(h, "unknown failure");
         return KX_ERR_DEVICE;
     }
 }
@@ -196,15 +210,8 @@ void kx_destroy(kx_model* m) {
 // The message is copied under the model's mutex into storage owned by the CALLING thread: another thread failing on
 // the same model afterwards cannot change or free what this pointer refers to.
 const char* kx_last_error(const kx_model* m) {
-    static thread_local std::string tls;
     if (!m || !m->m) return "null model";
-    try {
-        std::lock_guard<std::mutex> lk(m->m->mu);
-        tls = m->m->last_error;
-    } catch (...) {
-        return "unknown failure";
-    }
-    return tls.c_str();
+    return tls_last_error_model == m ? tls_last_error.c_str() : "";  // (the calling thread's own last failure on this model)
 }
 
 int kx_last_error_copy(const kx_model* m, char* buf, size_t buf_len) {
@@ -213,13 +220,7 @@ int kx_last_error_copy(const kx_model* m, char* buf, size_t buf_len) {
         set_err(buf, buf_len, "null model");
         return KX_ERR_INVALID;
     }
-    try {
-        std::lock_guard<std::mutex> lk(m->m->mu);
-        set_err(buf, buf_len, m->m->last_error);
-    } catch (...) {
-        set_err(buf, buf_len, "unknown failure");
-        return KX_ERR_DEVICE;
-    }
+    set_err(buf, buf_len, tls_last_error_model == m ? tls_last_error : std::string());
     return KX_OK;
 }
 

@@ -138,7 +138,6 @@ class Model {
     const Tap* find_tap(const std::string& name) const;
 
     std::mutex mu;
-    std::string last_error;
     uint64_t utt_base = 0;
     void set_lanes(int n) { lanes_cfg_ = n < 0 ? 0 : (n > N_LANES ? N_LANES : n); }
     int conv_mode = CONV_F16X3;

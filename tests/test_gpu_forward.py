@@ -316,25 +316,43 @@ def test_device_entry_point_rejects_bad_ids(hip_model):
 
 
 def test_last_error_is_a_per_thread_copy(hip_model):
-    """kx_last_error returns storage of the calling thread; concurrent failures on one model do not tear it."""
+    """kx_last_error is the CALLING thread's own last failure on the model: with three threads on one model -- two failing
+    with different messages, one succeeding all the time -- nobody's message is blanked by another thread's success or
+    replaced by another thread's failure."""
     import threading
     from kokorox_amd import hip_koko as hk
+    ids, styles = _inputs([6], seed0=900)
     style = [0.0] * 256
-    seen = []
+    seen = {"id": [], "speed": []}
+    ok = []
 
-    def worker(tok):
-        for _ in range(20):
+    def bad_id():
+        for _ in range(15):
             try:
-                hip_model.infer([[0, tok, 0]], [style], 1.0)
+                hip_model.infer([[0, 500, 0]], [style], 1.0)
             except hk.KokoroxHipError as e:
-                seen.append(str(e))
+                seen["id"].append(str(e))
 
-    th = [threading.Thread(target=worker, args=(t,)) for t in (500, 900, 1234)]
+    def bad_speed():
+        for _ in range(15):
+            try:
+                hip_model.infer([[0, 5, 0]], [style], -1.0)
+            except hk.KokoroxHipError as e:
+                seen["speed"].append(str(e))
+
+    def good():
+        for _ in range(15):
+            ok.append(hip_model.infer([list(ids[0])], [list(styles[0])], 1.0, seed=1).shape[0])
+
+    th = [threading.Thread(target=f) for f in (bad_id, bad_speed, good)]
     for t in th:
         t.start()
     for t in th:
-        t.join(timeout=120)
-    assert len(seen) == 60 and all("token id outside" in m for m in seen)
+        t.join(timeout=300)
+    assert len(seen["id"]) == 15 and all("token id outside" in m for m in seen["id"]), seen["id"][:3]
+    assert len(seen["speed"]) == 15 and all("speed must be" in m for m in seen["speed"]), seen["speed"][:3]
+    assert len(ok) == 15 and len(set(ok)) == 1
+    assert hip_model.last_error() == ""  # (this thread has not failed)
 
 
 def test_activation_prescale_and_diagnostics_cover_every_conv(hip_model):
