@@ -30,8 +30,12 @@ def _newer(target: str, deps) -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
+LAST_BUILD = {"compiled": [], "reused": [], "linked": False}  # what the last build_library() call did (build() reports it)
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP translation unit and link the shared library; returns its path."""
+    LAST_BUILD["compiled"], LAST_BUILD["reused"], LAST_BUILD["linked"] = [], [], False
     os.makedirs(LIB_DIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
@@ -41,6 +45,9 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         objs.append(o)
         if force or not _newer(o, [s] + hdrs + [os.path.join(CSRC, d) for d in EXTRA_DEPS.get(src, [])]):
             jobs.append([_hipcc(), *FLAGS, "-c", s, "-o", o])
+            LAST_BUILD["compiled"].append(src)
+        else:
+            LAST_BUILD["reused"].append(src)
     if jobs:
         # the translation units are independent: compile them side by side (conv_f16x3.hip alone is half the time)
         from concurrent.futures import ThreadPoolExecutor
@@ -57,6 +64,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
+        LAST_BUILD["linked"] = True
     return LIB_PATH
 
 

@@ -105,7 +105,7 @@ struct DevMem {
 
 extern "C" {
 
-const char* kx_version(void) { return "kokorox-hip 0.1 (gfx950; conv modes: f16x3 split MFMA [default], f32 MFMA)"; }
+const char* kx_version(void) { return "kokorox-hip 0.3 (gfx950; conv modes: f16x3 split MFMA [default], f32 MFMA, f16 reduced precision [opt-in])"; }
 
 int kx_init(int device_id, char* err, size_t err_len) {
     return guarded_free(err, err_len, [&] { check_device(device_id); });
