@@ -446,7 +446,10 @@ static void launch_inst16(const ConvArgs& a, int B, int max_cols, hipStream_t s)
 //   256-column tiles would not even give every CU one workgroup) 128 x (4 x 1): half the tile, but each wave still
 //   spans 128 columns, so the fused InstanceNorm partial sums cover the same column groups in the same order as with
 //   the 256-wide tile and results stay bit-identical across batch sizes.
-void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int stride, int* bn, int* wn, int ws_force) {
+// stats: the launch fuses InstanceNorm partial sums into its epilogue.  Their slots must then be 128 columns wide whatever the
+// launch geometry (an utterance's sums are added in the same order alone and beside a longer one: batch invariance), so the
+// 2 x 2-wave tile of short sequences (64-column slots) is not taken.
+void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int stride, int* bn, int* wn, int ws_force, bool stats) {
     static const int force = env_int("KX_BN", 0);
     if (ws_force == 2 && conv16_da_eligible(BM, K, dil, stride, 0)) {  // test hook: the direct-A kernel whatever the grid
         *bn = 256; *wn = 2;
@@ -454,7 +457,7 @@ void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int
     }
     if (BM != 128) {
         *bn = 256; *wn = 4;
-    } else if (force == 128 || max_cols <= 160) {
+    } else if ((force == 128 || max_cols <= 160) && !stats) {
         *bn = 128; *wn = 2;
     } else if ((long)((max_cols + 255) / 256) * ((Cout + 127) / 128) * B < 256 && force != 256) {
         *bn = 128; *wn = 1;
@@ -504,7 +507,7 @@ void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStre
         }
         KX_REQUIRE(a.epi != EPI_GELU_NEW, "conv1d f16x3: gelu epilogue exists only for k=1 GEMMs with >= 48 input channels");
         int bn, wn;
-        conv16_pick_tile(BM, max_cols, B, a.Cout, a.K, a.dil, a.stride, &bn, &wn, a.ws_force);
+        conv16_pick_tile(BM, max_cols, B, a.Cout, a.K, a.dil, a.stride, &bn, &wn, a.ws_force, a.stat_part != nullptr);
         if (bn == 128 && wn == 1 && conv16_use_da(BM, a.K, a.dil, a.stride, a.merge_T > 0) && a.ws_force != 1)
             launch_conv1d_f16x3_da(a, B, max_cols, s, 128);  // (test hook mode 2 keeps the LDS-DMA form for comparison)
         else if (bn == 128 && wn == 1)

@@ -120,7 +120,7 @@ size_t packed_conv_floats(int rows, int Cin, int K, int BM);
 enum ConvMode { CONV_F32 = 0, CONV_F16X3 = 1, CONV_F16X3_LDS = 2, CONV_F16X3_DA = 3, CONV_F16 = 4 };  // (2, 3: test hook only: f16x3 kept on the LDS-DMA kernel forms of conv_f16x3.hip / forced through conv_f16x3_da.hip)
 void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStream_t s);
 void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int stride, int* bn, int* wn,
-                      int ws_force = 0);  // (conv_f16x3.hip)
+                      int ws_force = 0, bool stats = false);  // (conv_f16x3.hip)
 // conv_f16x3_da.hip: the 128 x 256 tile with the weight fragments loaded from global memory straight into registers
 bool conv16_use_da(int BM, int K, int dil, int stride, int merged);       // eligible AND switched on (default; KX_DA=0 turns it off)
 bool conv16_da_eligible(int BM, int K, int dil, int stride, int merged);  // shape fits the kernel

@@ -504,7 +504,7 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
         const int max_c = out.Lmax;
         int bn, wn;
         if (f16) {
-            conv16_pick_tile(w.BM, max_c, B_, w.rows, w.K, o.dil, o.stride, &bn, &wn);
+            conv16_pick_tile(w.BM, max_c, B_, w.rows, w.K, o.dil, o.stride, &bn, &wn, 0, true);
         } else {
             bn = conv_bn(w.BM);
             wn = w.BM == 128 ? 2 : 4;
@@ -679,11 +679,20 @@ void Model::adain_resblk(const std::string& name, const T& x, const T& out, bool
     } else {
         KX_REQUIRE(!upsample && x.C == out.C, "internal: identity shortcut needs equal shapes");
     }
+    // InstanceNorm partial sums of t1 (normalised by norm2 below) and of the block's output (normalised by the next block's
+    // norm1 when that block reads exactly this tensor) leave the conv epilogues, as in the generator: no separate pass
+    auto part_for = [&](const T& t) -> float2* {
+        const size_t n = (size_t)B_ * t.C * (t.Lmax / 64 + 4);
+        return stats_arena_ ? static_cast<float2*>(stats_arena_->alloc(n * sizeof(float2))) : nullptr;
+    };
+    float2* part_t1 = part_for(t1);
+    float2* part_out = part_for(out);
     stats(x, name + ".norm1");
     if (!upsample) {
         ConvOpts o;
         o.nmean = nmean_; o.nscale = nscale_; o.nshift = nshift_;
         o.act = ACT_LEAKY; o.slope = 0.2f; o.pad = 1;
+        o.stat_part = part_t1;
         conv(c1, x, t1, o);
     } else {
         T p = out;
@@ -695,6 +704,7 @@ void Model::adain_resblk(const std::string& name, const T& x, const T& out, bool
                             wt(name + ".pool.bias"), p.p, p.bs, p.ld, x.len, B_, x.Lmax, stream_);
         ConvOpts o;
         o.pad = 1;
+        o.stat_part = part_t1;
         conv(c1, p, t1, o);
     }
     stats(t1, name + ".norm2");
@@ -703,6 +713,7 @@ void Model::adain_resblk(const std::string& name, const T& x, const T& out, bool
     o.act = ACT_LEAKY; o.slope = 0.2f; o.pad = 1;
     o.resid = res;
     o.out_mul = RSQRT2;
+    o.stat_part = part_out;
     wait_here(ev_sc);  // (the shortcut ran beside conv1)
     conv(c2, t1, out, o);
 }
