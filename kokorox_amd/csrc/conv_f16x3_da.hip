@@ -441,7 +441,10 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
 #ifndef KX_DA_I0_MID
 #define KX_DA_I0_MID 3   // k = 5 .. 8
 #endif
-        constexpr int I0 = KT >= 9 ? KX_DA_I0_LONG * NT : (KT >= 5 ? KX_DA_I0_MID * NT : NT);
+#ifndef KX_DA_I0_SHORT_T8
+#define KX_DA_I0_SHORT_T8 8  // k < 5: tiles (of the 256-column form; scaled by NT / 8) before the first transform part
+#endif
+        constexpr int I0 = KT >= 9 ? KX_DA_I0_LONG * NT : (KT >= 5 ? KX_DA_I0_MID * NT : KX_DA_I0_SHORT_T8 * NT / 8);
         for (int ch = 0; ch < n_chunks; ++ch) {
             const bool more = ch + 1 < n_chunks;
             static_for<0, TILES>([&](auto ic) __attribute__((always_inline)) {
