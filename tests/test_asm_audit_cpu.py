@@ -127,6 +127,15 @@ def test_direct_a_conv_assembly(tmp_path, src):
         want = hu + 3 + (1 if act == 2 else 0)  # raw_ops with the three InstanceNorm parameter loads present
         sizes = _prefetch_batches(lines)
         assert sizes and all(sz == want for sz in sizes), f"{name}: input prefetch is {sizes} loads, raw_ops assumes {want}"
+        # instruction budget of the unrolled main loops (text between the first and the last MFMA of the chunk body): vector
+        # instructions per MFMA.  The matrix pipe hides ~5 issue slots per 32-cycle MFMA (MI355X_MICROARCH.md); the k = 11
+        # form must stay well inside that, and none of the forms may quietly grow (round 3: 2.1 / 3.3 / 7.3 at 256 columns)
+        if kt > 0 and src == "conv_f16x3_da.hip":
+            mf = [i for i, ln in enumerate(lines) if "v_mfma" in ln]
+            body = lines[mf[0]:mf[-1] + 1]
+            valu = sum(1 for ln in body if re.match(r"\s*v_(?!mfma)", ln))
+            budget = {11: 3.0, 7: 4.5, 3: 9.5}[kt]
+            assert valu / len(mf) <= budget, f"{name}: {valu / len(mf):.2f} vector instructions per MFMA in the main loop (budget {budget})"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
