@@ -40,7 +40,12 @@ __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi_pk, 
     v[0] = __builtin_amdgcn_fmed3f(v0, -65504.f, 65504.f);
     v[1] = __builtin_amdgcn_fmed3f(v1, -65504.f, 65504.f);
     const half2v h2 = __builtin_convertvector(v, half2v);          // one v_cvt_pk_f16_f32
-    const float2v d = v - __builtin_convertvector(h2, float2v);
+    // (the two residuals as SCALAR subtractions: written as one float2 expression they become a v_pk_add_f32, and packed f32
+    // vector instructions are slow beside MFMAs on gfx950 -- MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+    float2v d;
+    d[0] = v[0] - (float)h2[0];
+    d[1] = v[1] - (float)h2[1];
+    asm volatile("" : "+v"(d[0]));  // (keeps the SLP vectoriser from re-packing the pair)
     const half2v l2 = __builtin_convertvector(d, half2v);
     hi_pk = __builtin_bit_cast(unsigned, h2);
     lo_pk = __builtin_bit_cast(unsigned, l2);

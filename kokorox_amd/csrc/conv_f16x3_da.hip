@@ -168,9 +168,12 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         const int c = ch * CK16 + g * 8 + (lane & 7);
         const int cc = c < cmax_in ? c : cmax_in;
         const float m = nm_src[cc], sc = ns_src[cc], sh = nh_src[cc];
+        // (channels past the end of a partial last chunk get scale = shift = 0: their transformed value is exactly 0 through
+        // every activation, so the per-element code needs no channel test)
+        const bool cvalid = c <= cmax_in;
         pv[0] = has_norm ? m : 0.f;
-        pv[1] = has_norm ? sc : 1.f;
-        pv[2] = has_norm ? sh : 0.f;
+        pv[1] = cvalid ? (has_norm ? sc : 1.f) : 0.f;
+        pv[2] = (cvalid && has_norm) ? sh : 0.f;
         pv[3] = (ACT == ACT_SNAKE) ? a.alpha[cc] : 1.f;  // (its reciprocal is taken when the chunk is transformed: a
                                                           // division here would wait for the load on the spot)
     };
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
             for (int q = 0; q < 2; ++q) {
                 const int c = 2 * c2 + q;
                 const float y = in_act<ACT>(__builtin_fmaf(x8[c] - o.m[c], o.s[c], o.h[c]), a.slope, o.al[c], o.ial[c]);  // (explicit fma: see conv_epilogue.h)
-                y2[q] = y * ((ch * CK16 + g * 8 + c <= cmax_in) ? keep : 0.f);
+                y2[q] = y * keep;
             }
             split_pair(y2[0], y2[1], hp[c2], lp[c2]);
         }
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
                 const float al = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al_or_rcp), cl));
                 const float ial = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al_or_rcp), cl + 8));
                 const float y = in_act<ACT>(__builtin_fmaf(x8[c] - m, sc, sh), a.slope, al, ial);
-                y2[q] = y * ((ch * CK16 + g * 8 + cl <= cmax_in) ? keep : 0.f);
+                y2[q] = y * keep;
             }
             split_pair(y2[0], y2[1], hp[c2], lp[c2]);
         }
@@ -276,6 +279,9 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, praw[1]), cq));
         const float sh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, praw[2]), cq));
         xt_ = __builtin_fmaf(raw[j][cr] - m, sc, sh);
+        // (an opaque hand-over: two half-units on one tile otherwise get SLP-packed into v_pk_add_f32 / v_pk_fma_f32, which
+        // are slow beside MFMAs on gfx950 -- seen in the generated code of the leaky k = 3 form)
+        asm volatile("" : "+v"(xt_));
         if (ACT == ACT_SNAKE) {
             const float al = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al_rcp_x), cq));
             const float t = al * xt_;
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
             y = in_act<ACT>(xt_, a.slope, 1.f, 1.f);
         }
         const float keep = ((okmask >> j) & 1u) ? a.x_prescale : 0.f;
-        y = y * ((ch * CK16 + g * 8 + cq <= cmax_in) ? keep : 0.f);
+        y = y * keep;
         if (half == 0) {
             y_carry = y;
         } else {
