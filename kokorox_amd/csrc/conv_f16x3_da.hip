@@ -268,11 +268,13 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     float xt_ = 0.f, xz_ = 0.f;  // (state of the element in flight: the affine value, then z = r^2 / sin^2)
     // One element of the transform in three parts, placed behind the three MFMAs of a column tile.  The arithmetic is that
     // of emit8 / in_act / sin_sq, operation for operation (results must not depend on where a chunk was transformed).
-    // U: unit (column block U / 4, channel pair U % 4), half: element of the pair; both constants once inlined.
+    // U: unit (whole blocks: channel pair U / NJF of column block U % NJF, so that consecutive units are the SAME channel pair in
+    // the wave's blocks and share their per-channel parameters -- five v_readlane per element otherwise), half: element of the
+    // pair; both constants once inlined.
     auto xform_a = [&](const int U, const int half, int ch) __attribute__((always_inline)) {
-        // units 0 .. 4 NJF - 1: whole blocks (block U / 4, channel pair U % 4); the last two: the split block's two pairs
+        // units 0 .. 4 NJF - 1: whole blocks (block U % NJF, channel pair U / NJF); the last two: the split block's two pairs
         const bool split = W64 && U >= 4 * NJF;
-        const int j = split ? NJF : U / 4, cr = split ? 2 * (U - 4 * NJF) + half : 2 * (U % 4) + half;  // element in raw[j]
+        const int j = split ? NJF : U % NJF, cr = split ? 2 * (U - 4 * NJF) + half : 2 * (U / NJF) + half;  // element in raw[j]
         const int cq = split ? jb * 4 + cr : cr;                                                         // channel of the octet
         if (U == 0 && half == 0) al_rcp_x = (lane & 8) ? 1.0f / praw[3] : praw[3];
         const float m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, praw[0]), cq));
@@ -304,8 +306,8 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     };
     auto xform_c = [&](const int U, const int half, uint4* Xb, int ch) __attribute__((always_inline)) {
         const bool split = W64 && U >= 4 * NJF;
-        const int j = split ? NJF : U / 4;
-        const int c2 = split ? jb * 2 + (U - 4 * NJF) : U % 4;  // channel pair of the octet = dword of the 16-byte slot
+        const int j = split ? NJF : U % NJF;
+        const int c2 = split ? jb * 2 + (U - 4 * NJF) : U / NJF;  // channel pair of the octet = dword of the 16-byte slot
         const int cq = 2 * c2 + half;
         float y;
         if (ACT == ACT_SNAKE) {
