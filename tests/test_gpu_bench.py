@@ -42,3 +42,27 @@ def test_bench_two_ranks_rehearsal():
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert abs(d["audio_s_per_step"] - 2 * 4 * 10.55) < 1e-6
+
+
+def test_bench_blocks_and_single_process_replicas():
+    """The secondary blocks of the N = 1 line (serving leg = BASELINE configs[4], reduced-precision mode = configs[2]'s
+    "bf16") and the single-process form of the N-GPU run (`--replicas`, kx_create_replicas + one host thread per model),
+    rehearsed with two replicas on the one GPU."""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--batch", "4", "--cpu-utts", "0",
+                        "--free-run", "0", "--pcie", "0"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    s = d["serve"]
+    assert s["clients"] == 32 and s["requests"] == 128 and s["aggregate_rtf"] > 0 and s["latency_p99_ms"] >= s["latency_p50_ms"] > 0
+    assert s["batches"] < s["requests"] and s["max_batch"] > 1
+    rp = d["reduced_precision"]
+    assert rp["value"] > 0 and rp["roofline"]["frac"] > 0 and "f16" in rp["mode"]
+    assert "traffic_source" in d["roofline"]
+    env = dict(os.environ, KX_REPLICA_IDS="0,0")
+    r = subprocess.run([sys.executable, "bench.py", "--replicas", "2", "--steps", "1", "--warmup", "1", "--batch", "4", "--serve", "0"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert REQUIRED <= set(d)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["weight_broadcast_s"] > 0
+    assert abs(d["audio_s_per_step"] - 2 * 4 * 10.55) < 1e-6 and "kx_create_replicas" in d["config"]["parallelism"]
