@@ -263,6 +263,14 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     // exactly its own duration (7.2 of 24.8 ms on the k = 11 launches; dropping it, loads kept: 17.7 ms): the partner
     // workgroup's MFMAs do not fill the gap (two co-resident workgroups that start together stay in phase).  A wave's own
     // MFMAs do: the matrix pipe runs an MFMA for 32 cycles while the wave's vector instructions keep issuing.
+#ifdef KX_DA_NO_XFORM
+    auto keep_elem = [&](const int hh) __attribute__((always_inline)) {
+        const int U = hh / 2, half = hh & 1;
+        const bool split = W64 && U >= 4 * NJF;
+        const int j = split ? NJF : U % NJF, cr = split ? 2 * (U - 4 * NJF) + half : 2 * (U / NJF) + half;
+        asm volatile("" ::"v"(raw[j][cr]), "v"(praw[0]), "v"(praw[1]), "v"(praw[2]), "v"(praw[3]));
+    };
+#endif
     float al_rcp_x = 1.f;  // (alpha | 1 / alpha by lane, set by the first part of a chunk's transform)
     float y_carry = 0.f;   // (first element of a pair, from half 0 to half 1)
     float xt_ = 0.f, xz_ = 0.f;  // (state of the element in flight: the affine value, then z = r^2 / sin^2)
@@ -378,7 +386,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     // issued, so a fragment is requested two whole steps before its use and nothing ever moves between registers.  The
     // (chunk, tap) walk is flattened and unrolled by three for that.
 #ifdef KX_DA_STAMPS  // diagnostic build only (tools/stamp_timeline.py): per-workgroup phase stamps; nothing reads them back
-    unsigned long long st0 = 0, st1 = 0, st2 = 0, cyc0 = 0;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, cyc0 = 0, acc_bar = 0;
     if (a.stamps) {
         st0 = __builtin_amdgcn_s_memrealtime();
         cyc0 = __builtin_readcyclecounter();
@@ -453,6 +461,15 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
 #define KX_DA_I0_SHORT_T8 8  // k < 5: tiles (of the 256-column form; scaled by NT / 8) before the first transform part
 #endif
         constexpr int I0 = KT >= 9 ? KX_DA_I0_LONG * NT : (KT >= 5 ? KX_DA_I0_MID * NT : KX_DA_I0_SHORT_T8 * NT / 8);
+#ifndef KX_DA_GROUP_LONG
+#define KX_DA_GROUP_LONG 4  // tiles per scheduling region, k >= 9
+#endif
+#ifndef KX_DA_GROUP_MID
+#define KX_DA_GROUP_MID 2   // k = 5 .. 8
+#endif
+        constexpr int G0 = (P1 || KT < 5) ? 1 : (KT >= 9 ? KX_DA_GROUP_LONG : KX_DA_GROUP_MID);
+        constexpr int G = G0 < NT ? G0 : NT;
+        static_assert(NT % G == 0, "a group of tiles does not straddle a tap");
         for (int ch = 0; ch < n_chunks; ++ch) {
             const bool more = ch + 1 < n_chunks;
             static_for<0, TILES>([&](auto ic) __attribute__((always_inline)) {
@@ -462,7 +479,11 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
                 if constexpr (n == 0) wait_A(ages[sl], ahs[sl], als[sl]);
                 const half8 ah = __builtin_bit_cast(half8, ahs[sl]), al = __builtin_bit_cast(half8, als[sl]);
                 if constexpr (ip < TILES) load_tile(ip / NT, ip % NT, fh[e2], fl[e2]);
-                __builtin_amdgcn_sched_barrier(0);
+                // Scheduling regions of G tiles.  Measured (tools/probes/mfma_valu_coissue.hip): with two waves per SIMD up to ~4
+                // independent vector instructions per MFMA are free, 8 cost their full time -- and a half-unit dealt out as
+                // 3 x 9 behind the three MFMAs of ONE tile cost exactly its own duration (stamps with and without the transform:
+                // 19.8 k against 17.2 k cycles per k = 11 chunk).  So a half-unit is spread over the 3 G MFMAs of a group of tiles.
+                if constexpr (i % G == 0) __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!P1) {
                     acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fh[e], acc[0][n], 0, 0, 0);
                     acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fl[e], acc[0][n], 0, 0, 0);
@@ -474,18 +495,48 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
                 constexpr int h1 = i + 1 > I0 ? ((i + 1 - I0) * HU) / (TILES - I0) : 0;
                 // (no run-time condition around them: a branch would put them in a block of their own, behind the MFMAs
                 // instead of between them)
-                if constexpr (h1 > h0) {
+#ifdef KX_DA_NO_XFORM  // (diagnostic build: the transform's vector work and LDS writes dropped, image stale: compare CYCLES, not time)
+                constexpr bool do_xform = false;
+#else
+                constexpr bool do_xform = true;
+#endif
+#ifdef KX_DA_NO_XFORM
+                // (the loads stay alive and counted -- the hand-counted ring waits assume every prefetch batch -- only the vector
+                // work and the LDS writes go)
+                if constexpr (h1 > h0) keep_elem(h0);
+                if constexpr (h1 > h0 + 1) keep_elem(h0 + 1);
+#endif
+                if constexpr (do_xform && h1 > h0) {
                     xform_a(h0 / 2, h0 & 1, ch + 1);
                     xform_b();
                     xform_c(h0 / 2, h0 & 1, Xs + (cur ^ 1) * XBUF, ch + 1);
                 }
-                if constexpr (h1 > h0 + 1) {
+                if constexpr (do_xform && h1 > h0 + 1) {
                     xform_a((h0 + 1) / 2, (h0 + 1) & 1, ch + 1);
                     xform_b();
                     xform_c((h0 + 1) / 2, (h0 + 1) & 1, Xs + (cur ^ 1) * XBUF, ch + 1);
                 }
                 static_assert(h1 - h0 <= 2, "at most two half-units per tile");
-                if constexpr (P1) {  // (one MFMA per tile: the vector work follows it in one piece)
+                if constexpr (G > 1) {
+                    if constexpr (i % G == G - 1) {  // the pipeline of the whole group, written at its end
+                        constexpr int ig = i - (G - 1);
+                        constexpr int hg0 = ig > I0 ? ((ig - I0) * HU) / (TILES - I0) : 0;
+                        constexpr int nh = h1 - hg0;                                   // half-units in the group
+                        constexpr int per = nh > 0 ? (nh * 27 + 3 * G - 1) / (3 * G) : 0;  // vector instructions per MFMA
+#pragma unroll
+                        for (int tg = 0; tg < G; ++tg) {
+                            // (the fragment reads of the later tiles of the group stay ahead of their tile's MFMAs; opening EVERY tile
+                            // with the next tile's reads measured the same -- 19.46 k against 19.49 k ticks per k = 11 chunk -- and made
+                            // the 128-column k = 11 form spill)
+                            if (tg > 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                            for (int k3 = 0; k3 < 3; ++k3) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                if (per > 0) __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
+                            }
+                        }
+                    }
+                } else if constexpr (P1) {  // (one MFMA per tile: the vector work follows it in one piece)
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 } else if constexpr (h1 - h0 == 1) {
 #pragma unroll
@@ -500,7 +551,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
                         __builtin_amdgcn_sched_group_barrier(0x002, 18, 0);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (i % G == G - 1) __builtin_amdgcn_sched_barrier(0);
                 if constexpr (n == NT - 1) {
                     // refill this slot: with the tap three further on, or (its last use in the chunk) with the next
                     // chunk's tap of the same slot number
@@ -513,7 +564,14 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
                 }
             });
             if (more) {
+#ifdef KX_DA_STAMPS
+                unsigned long long tb0 = 0;
+                if (a.stamps) tb0 = __builtin_amdgcn_s_memrealtime();
+#endif
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef KX_DA_STAMPS
+                if (a.stamps) acc_bar += __builtin_amdgcn_s_memrealtime() - tb0;
+#endif
                 cur ^= 1;
                 if (ch + 2 < n_chunks && !(a.dbg & 1)) {
                     load_raw(ch + 2);
@@ -635,7 +693,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         o[4] = __builtin_amdgcn_s_getreg(63492);  // HW_REG_HW_ID
         o[5] = __builtin_readcyclecounter() - cyc0;
         o[6] = __builtin_amdgcn_s_getreg(63508);  // HW_REG_XCC_ID
-        o[7] = 0;
+        o[7] = acc_bar;  // 10 ns ticks spent in the chunk barriers of the main loop (wave 0)
     }
 #endif
 }

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void probe(const uint4* frag_src, int steps
                     yb[o] = acc[n][e] + rb[o];
                 }
         }
-    } else {
+    } else if constexpr (SHAPE == 1) {
         f32x4 acc[2][16];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -92,6 +92,72 @@ __global__ __launch_bounds__(256, 2) void probe(const uint4* frag_src, int steps
                         yb[o] = acc[i][n][q] + rb[o];
                     }
         }
+    } else if constexpr (SHAPE == 2 || SHAPE == 4) {
+        // 32x32x16, wave tile 64 rows x 128 columns (2 x 2 waves): a fragment read feeds six MFMAs -- half the LDS reads per FLOP
+        // (SHAPE 4: the same without any LDS read in the loop, fragments fixed in registers)
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        const half8 a2_hi = __builtin_bit_cast(half8, frag_src[tid + 512]), a2_lo = __builtin_bit_cast(half8, frag_src[tid + 768]);
+        half8 bh0 = __builtin_bit_cast(half8, lds[lane]), bl0 = __builtin_bit_cast(half8, lds[64 + lane]);
+        for (int s = 0; s < steps16; ++s) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                half8 bh = bh0, bl = bl0;
+                if constexpr (SHAPE == 2) {
+                    bh = __builtin_bit_cast(half8, lds[((s * 4 + n) * 2 * 64 + lane) & 2047]);
+                    bl = __builtin_bit_cast(half8, lds[((s * 4 + n) * 2 * 64 + 64 + lane) & 2047]);
+                } else {
+                    asm volatile("" : "+v"(bh0), "+v"(bl0));
+                }
+                acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh, acc[0][n], 0, 0, 0);
+                acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl, acc[0][n], 0, 0, 0);
+                acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bh, acc[0][n], 0, 0, 0);
+                acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2_lo, bh, acc[1][n], 0, 0, 0);
+                acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2_hi, bl, acc[1][n], 0, 0, 0);
+                acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2_hi, bh, acc[1][n], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sink += acc[i][j][e];
+    } else {
+        // 16x16x32, wave tile 64 rows x 128 columns: a fragment read feeds twelve MFMAs
+        f32x4 acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        half8 ah[4], al[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ah[i] = __builtin_bit_cast(half8, frag_src[tid + 512 * i]);
+            al[i] = __builtin_bit_cast(half8, frag_src[tid + 512 * i + 256]);
+        }
+        for (int s = 0; s < steps16 / 2; ++s) {
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                const half8 bh = __builtin_bit_cast(half8, lds[((s * 8 + n) * 2 * 64 + lane) & 2047]);
+                const half8 bl = __builtin_bit_cast(half8, lds[((s * 8 + n) * 2 * 64 + 64 + lane) & 2047]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][n], 0, 0, 0);
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc[i][n], 0, 0, 0);
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc[i][n], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sink += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     }
     if (tid == 0) {
         clk[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime() - t0;
@@ -118,14 +184,18 @@ int main(int argc, char** argv) {
     hipMalloc(&res, (size_t)n_wg * 128 * ld * 4);
     hipMemset(res, 0, (size_t)n_wg * 128 * ld * 4);
     hipMalloc(&clk, n_wg * 16);
+    const char* names[5] = {"32x32x16 wave 32x256", "16x16x32 wave 32x256", "32x32x16 wave 64x128", "16x16x32 wave 64x128", "32x32x16 64x128 no LDS reads"};
     for (int e = 0; e < 2; ++e)
-        for (int shape = 0; shape < 2; ++shape) {
+        for (int shape = 0; shape < (e ? 2 : 5); ++shape) {
             hipEvent_t e0, e1;
             hipEventCreate(&e0);
             hipEventCreate(&e1);
             auto launch = [&]() {
                 if (shape == 0) hipLaunchKernelGGL(probe<0>, dim3(n_wg), dim3(256), 32768, 0, frag, steps16, y, res, ld, e, clk);
-                else hipLaunchKernelGGL(probe<1>, dim3(n_wg), dim3(256), 32768, 0, frag, steps16, y, res, ld, e, clk);
+                else if (shape == 1) hipLaunchKernelGGL(probe<1>, dim3(n_wg), dim3(256), 32768, 0, frag, steps16, y, res, ld, e, clk);
+                else if (shape == 2) hipLaunchKernelGGL(probe<2>, dim3(n_wg), dim3(256), 32768, 0, frag, steps16, y, res, ld, e, clk);
+                else if (shape == 3) hipLaunchKernelGGL(probe<3>, dim3(n_wg), dim3(256), 32768, 0, frag, steps16, y, res, ld, e, clk);
+                else hipLaunchKernelGGL(probe<4>, dim3(n_wg), dim3(256), 32768, 0, frag, steps16, y, res, ld, e, clk);
             };
             for (int i = 0; i < 20; ++i) launch();  // ~ 50 ms of load first: the clock settles
             hipDeviceSynchronize();
@@ -140,8 +210,8 @@ int main(int argc, char** argv) {
             double mhz = 0;
             for (int i = 0; i < n_wg; ++i) mhz += (double)c[2 * i + 1] / ((double)c[2 * i] / 100.0);
             const double flops = (double)n_wg * 4 * steps16 * 8 * 3 * (32.0 * 32 * 16 * 2);
-            printf("%s  %-12s %.3f ms per launch, %.0f TFLOP/s issued (%.0f algorithmic at 3 per product), shader clock %.0f MHz\n",
-                   e ? "M + stores" : "M only    ", shape ? "16x16x32" : "32x32x16", ms / 20, flops / (ms / 20 * 1e-3) / 1e12,
+            printf("%s  %-30s %.3f ms per launch, %.0f TFLOP/s issued (%.0f algorithmic at 3 per product), shader clock %.0f MHz\n",
+                   e ? "M + stores" : "M only    ", names[shape], ms / 20, flops / (ms / 20 * 1e-3) / 1e12,
                    flops / 3 / (ms / 20 * 1e-3) / 1e12, mhz / n_wg);
         }
     return 0;
