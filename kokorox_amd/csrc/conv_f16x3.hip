@@ -374,7 +374,7 @@ static int env_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-static int conv16_cu_count() {
+int conv16_cu_count() {
     static int n = 0;
     if (n == 0) {
         int dev = 0;

@@ -239,6 +239,141 @@ __global__ __launch_bounds__(256, 3) void conv1d_f16x3_dag_kernel(const ConvArgs
     conv_store_tile<1, NT, EPI_ROWS, true>(a, acc, a.w_unscale, b, ct * BM + wave * 32, t0, r, h, ncols, Lout, tile_x, nullptr);
 }
 
+// ---- the narrow form for small grids: 128 rows x 32 columns per workgroup, no LDS ------------------------------------------
+// At batch 1 the ALBERT GEMMs have 128 columns in all: the 128 x 128 tile leaves 6 - 18 workgroups on 256 CUs, each walking
+// the whole K axis alone (43 super-chunks with a barrier each for the 768 x 2048 layer: 35 us per launch, 60 launches on the
+// forward's critical path).  Here a workgroup takes 32 columns, so four times as many CUs work, and nothing is staged: lane
+// (column lane & 31, channel octet lane >> 5) loads the 8 input values of its B fragment itself, applies the same activation
+// / padding / f16 split (xform values are those of xform_pair, operation for operation) and feeds the wave's three MFMAs; the
+// four waves (32 rows each) repeat that split, which is cheaper than a barrier.  Weights and inputs come through a three-slot
+// register ring of inline-asm loads, ten per chunk (2 weight fragments + 8 input values), every one unconditional (chunks past
+// the end re-read the last chunk and are multiplied by zero), so the waits are constants: vmcnt(10), the one younger slot.
+// Per accumulator the products are added in the order of the other forms: results are bit-identical to them.
+template <int ACT>
+__global__ __launch_bounds__(256, 4) void conv1d_f16x3_dagn_kernel(const ConvArgs a) {
+    constexpr int BM = 128, BN = 32;
+    constexpr int tap_units = 4 * BM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, tile_x = blockIdx.x, ct = blockIdx.y;
+    const int t0 = tile_x * BN;
+    const bool merged = a.merge_T > 0;
+    const int Lin = merged ? a.merge_B * a.merge_T : a.in_len.lens[b] * a.in_len.mul + a.in_len.add;
+    const int Lout = merged ? Lin : a.out_len.lens[b] * a.out_len.mul + a.out_len.add;
+    const int ncols = Lout;
+    if (t0 >= ncols) return;
+    const int n_chunks = a.n_chunks16;
+    const int n_super = (n_chunks + 2) / 3;
+
+    // the lane's input column (a 1-tap GEMM has no padding)
+    long xoff;
+    bool pok;
+    {
+        const int p = t0 + r;
+        if (merged) {
+            const int pc = p < Lin ? p : Lin - 1;
+            const int bb = pc / a.merge_T, tt = pc - bb * a.merge_T;
+            pok = p < Lin && tt < a.in_len.lens[bb];
+            xoff = (long)bb * a.x_bs + tt;
+        } else {
+            pok = p < Lin;
+            xoff = (long)b * a.x_bs + (p >= Lin ? Lin - 1 : p);
+        }
+    }
+    const float keep = pok ? a.x_prescale : 0.f;
+    const int cmax_in = a.Cin - 1;
+    // byte offsets of the lane's eight values from the first row of a chunk (checked < 2^31 at launch): a chunk's loads take a
+    // scalar base and these, no address arithmetic.  (Cin is a multiple of 16 here -- checked at launch -- so a chunk has no
+    // missing channels; the up to two chunks past the end that complete the last round of three re-read the last chunk and
+    // are multiplied by zero.)
+    unsigned voff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) voff[j] = (unsigned)(((long)(h * 8 + j) * a.x_ld + xoff) * 4);
+    const uint4* wlane = reinterpret_cast<const uint4*>(a.w16) + (long)ct * n_chunks * tap_units + h * BM + wave * 32 + r;
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    u32x4 ahs[3], als[3];
+    float raw[3][8];
+    // chunk c into a slot: ten vector loads, whatever c
+    auto load_chunk = [&](int c, u32x4& a_hi, u32x4& a_lo, float (&rw)[8]) __attribute__((always_inline)) {
+        const int cc = c < n_chunks ? c : n_chunks - 1;
+        const uint4* p = wlane + (long)cc * tap_units;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a_hi) : "v"(p) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a_lo) : "v"(p + 2 * BM) : "memory");
+        const float* base = a.x + (long)cc * CK16 * a.x_ld;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("global_load_dword %0, %1, %2" : "=v"(rw[j]) : "v"(voff[j]), "s"(base) : "memory");
+    };
+    // (the wait has no operands, a scheduling barrier follows, and only then are the registers handed on: conv_f16x3_da.hip)
+    auto wait_chunk = [&](const int n, u32x4& a_hi, u32x4& a_lo, float (&rw)[8]) __attribute__((always_inline)) {
+        if (n == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(a_hi), "+v"(a_lo), "+v"(rw[0]), "+v"(rw[1]), "+v"(rw[2]), "+v"(rw[3]), "+v"(rw[4]), "+v"(rw[5]), "+v"(rw[6]),
+                     "+v"(rw[7]));
+    };
+    // the lane's B fragment of chunk c from its eight input values
+    auto split8 = [&](int c, const float (&rw)[8], half8& bh, half8& bl) __attribute__((always_inline)) {
+        unsigned hp[4], lp[4];
+        const float kc = keep * (c < n_chunks ? 1.f : 0.f);
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2) {
+            const float y0 = in_act<ACT>(rw[2 * c2], a.slope, 1.f, 1.f) * kc;
+            const float y1 = in_act<ACT>(rw[2 * c2 + 1], a.slope, 1.f, 1.f) * kc;
+            split_pair(y0, y1, hp[c2], lp[c2]);
+        }
+        bh = __builtin_bit_cast(half8, make_uint4(hp[0], hp[1], hp[2], hp[3]));
+        bl = __builtin_bit_cast(half8, make_uint4(lp[0], lp[1], lp[2], lp[3]));
+    };
+
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.f;
+    load_chunk(0, ahs[0], als[0], raw[0]);
+    load_chunk(1, ahs[1], als[1], raw[1]);
+    load_chunk(2, ahs[2], als[2], raw[2]);
+    half8 bh, bl;
+    wait_chunk(20, ahs[0], als[0], raw[0]);
+    split8(0, raw[0], bh, bl);
+    for (int sc = 0; sc < n_super; ++sc) {
+        static_for_g<0, 3>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value, tn = (t + 1) % 3;
+            const int c = sc * 3 + t;
+            const half8 ah = __builtin_bit_cast(half8, ahs[t]), al = __builtin_bit_cast(half8, als[t]);
+            const half8 bh0 = bh, bl0 = bl;
+            // The three MFMAs of a chunk are a dependent chain on the one accumulator: each waits for the one before it, and
+            // the split of the NEXT chunk's fragment (slot tn: the only younger loads are slot t + 2's ten) fills the gaps.
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh0, acc[0][0], 0, 0, 0);
+            wait_chunk(10, ahs[tn], als[tn], raw[tn]);
+            split8(c + 1, raw[tn], bh, bl);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl0, acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh0, acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // slot t is free once its MFMAs are issued (they read ah / al when they issue)
+            load_chunk(c + 3, ahs[t], als[t], raw[t]);
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl)  // (the ring's last loads land in registers that stay reserved until here)
+        asm volatile("" ::"v"(ahs[sl]), "v"(als[sl]), "v"(raw[sl][0]), "v"(raw[sl][1]), "v"(raw[sl][2]), "v"(raw[sl][3]), "v"(raw[sl][4]),
+                     "v"(raw[sl][5]), "v"(raw[sl][6]), "v"(raw[sl][7]));
+    conv_store_tile<1, 1, EPI_ROWS, true>(a, acc, a.w_unscale, b, ct * BM + wave * 32, t0, r, h, ncols, Lout, tile_x, nullptr);
+}
+
+template <int ACT>
+static void launch_dagn_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
+    dim3 grid((max_cols + 31) / 32, (a.Cout + 127) / 128, a.merge_T > 0 ? 1 : B);
+    KX_REQUIRE(grid.x > 0 && grid.y > 0 && grid.y < 65536 && B > 0 && B < 65536, "conv1d f16x3 dag narrow: bad grid");
+    hipLaunchKernelGGL(conv1d_f16x3_dagn_kernel<ACT>, grid, dim3(256), 0, s, a);
+    KX_HIP(hipGetLastError());
+}
+
 template <int ACT>
 static void launch_dag_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
     auto kern = conv1d_f16x3_dag_kernel<ACT>;
@@ -254,6 +389,19 @@ void launch_conv1d_f16x3_dag(const ConvArgs& a, int B, int max_cols, hipStream_t
     KX_REQUIRE(a.n_chunks16 == (a.Cin + CK16 - 1) / CK16 && a.w16 != nullptr, "conv1d f16x3 dag: weights not packed");
     KX_REQUIRE(a.pad == 0, "conv1d f16x3 dag: a 1-tap GEMM has no padding");
     if (max_cols <= 0) return;
+    // fewer 128 x 128 tiles than CUs: the narrow form (KX_DAGN=0: never; results are bit-identical either way)
+    static const int narrow = getenv("KX_DAGN") ? atoi(getenv("KX_DAGN")) : 1;
+    const long wgs = (long)((max_cols + 127) / 128) * ((a.Cout + 127) / 128) * (a.merge_T > 0 ? 1 : B);
+    // (the narrow form: whole chunks only, and 32-bit byte offsets into the input)
+    const long x_span = ((long)a.x_bs * (a.merge_T > 0 ? a.merge_B : B) + (long)CK16 * a.x_ld) * 4;
+    const bool narrow_ok = a.Cin % CK16 == 0 && x_span < (1L << 31);
+    if (narrow_ok && (narrow == 2 || (narrow && wgs < conv16_cu_count()))) {
+        if (a.act == ACT_LEAKY)
+            launch_dagn_inst<ACT_LEAKY>(a, B, max_cols, s);
+        else
+            launch_dagn_inst<ACT_NONE>(a, B, max_cols, s);
+        return;
+    }
     if (a.act == ACT_LEAKY)
         launch_dag_inst<ACT_LEAKY>(a, B, max_cols, s);
     else

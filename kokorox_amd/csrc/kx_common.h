@@ -129,6 +129,7 @@ void launch_conv1d_f16x3_da(const ConvArgs& a, int B, int max_cols, hipStream_t 
 bool conv16_use_dag(const ConvArgs& a, int BM);       // eligible AND switched on (default; KX_DAG=0 turns it off)
 bool conv16_dag_eligible(const ConvArgs& a, int BM);
 void launch_conv1d_f16x3_dag(const ConvArgs& a, int B, int max_cols, hipStream_t s);
+int conv16_cu_count();  // CUs of the current device (conv_f16x3.hip)
 size_t packed_conv16_halves(int rows, int Cin, int K, int BM);
 float device_absmax(const float* p, long n, hipStream_t s);
 int pick_weight_shift(float absmax);

@@ -146,5 +146,15 @@ def test_direct_a_gemm_assembly(tmp_path):
         assert not any("scratch_" in ln for ln in lines), f"{name} spills"
         bad = _audit_no_touch_before_wait(lines)
         assert not bad, f"{name}: ring registers touched before their wait: {bad[:3]}"
+        if "dagn_kernel" in name:
+            # the narrow form: every wait of the loop is vmcnt(10) = "the one younger slot", so exactly ten vector loads
+            # (2 weight fragments + 8 input values) must lie between two consecutive waits, and nothing else may load or store
+            body = [ln.strip() for ln in lines]
+            waits = [i for i, ln in enumerate(body) if ln.startswith("s_waitcnt vmcnt(10)")]
+            assert len(waits) == 3, f"{name}: {len(waits)} ring waits in the unrolled round of three"
+            for a0, a1 in zip(waits, waits[1:]):
+                n = sum(1 for ln in body[a0:a1] if re.match(r"(global|buffer|flat|scratch)_(load|store|atomic)", ln))
+                assert n == 10, f"{name}: {n} vector-memory operations between two ring waits, the waits assume 10"
+            continue
         sizes = _prefetch_batches(lines)
         assert sizes and all(sz == 24 for sz in sizes), f"{name}: input prefetch is {sizes} loads, raw_ops assumes 24"

@@ -351,10 +351,14 @@ def test_direct_a_run_time_tap_forms_are_bit_identical_under_load():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,Cin,Cout,L", [(4, 768, 2048, 2100), (8, 640, 2048, 130), (3, 1090, 1024, 845), (2, 50, 256, 300)])
+@pytest.mark.parametrize("B,Cin,Cout,L", [(4, 768, 2048, 2100), (8, 640, 2048, 130), (3, 1090, 1024, 845), (2, 50, 256, 300),
+                                          # small grids (fewer 128 x 128 tiles than CUs): the narrow 128 x 32 form without LDS
+                                          (1, 768, 2304, 128), (1, 2048, 768, 100), (2, 640, 512, 70), (1, 128, 768, 33),
+                                          (1, 1090, 512, 90)])  # (a partial chunk: stays on the 128 x 128 form)
 def test_direct_a_gemm_is_bit_identical_to_virtual_tap_form(B, Cin, Cout, L):
-    """k = 1 GEMMs: conv_f16x3_dag.hip (the default) against the virtual-tap LDS-DMA form (test-hook mode 2 keeps it), bit for
-    bit, incl. channel counts that leave a partial 16-channel chunk and a partial three-chunk super-chunk; and against f64."""
+    """k = 1 GEMMs: conv_f16x3_dag.hip (the default: its 128 x 128 form on chip-filling grids, its narrow form on small ones)
+    against the virtual-tap LDS-DMA form (test-hook mode 2 keeps it), bit for bit, incl. channel counts that leave a partial
+    16-channel chunk and a partial three-chunk super-chunk; and against f64."""
     from kokorox_amd import hip_koko as hk
     rng = np.random.default_rng(Cin)
     x = rng.standard_normal((B, Cin, L), dtype=np.float32)

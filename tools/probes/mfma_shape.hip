@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256, 2) void probe(const uint4* frag_src, int steps
     half8 a_hi = __builtin_bit_cast(half8, frag_src[tid]), a_lo = __builtin_bit_cast(half8, frag_src[tid + 256]);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_readcyclecounter();
     float sink = 0.f;
-    if constexpr (SHAPE == 0) {
+    if constexpr (SHAPE == 0 || SHAPE == 5 || SHAPE == 6) {
         f32x16 acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -35,9 +35,25 @@ __global__ __launch_bounds__(256, 2) void probe(const uint4* frag_src, int steps
             for (int n = 0; n < 8; ++n) {
                 const half8 bh = __builtin_bit_cast(half8, lds[((s * 8 + n) * 2 * 64 + lane) & 2047]);
                 const half8 bl = __builtin_bit_cast(half8, lds[((s * 8 + n) * 2 * 64 + 64 + lane) & 2047]);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bh, acc[n], 0, 0, 0);
+                if constexpr (SHAPE == 0) {
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bh, acc[n], 0, 0, 0);
+                } else if constexpr (SHAPE == 5) {  // the B operand changes once per tile instead of twice
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bh, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl, acc[n], 0, 0, 0);
+                } else {  // A changes once per tile, and the next tile starts on the A it ended on (a_lo)
+                    if (n & 1) {
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bh, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl, acc[n], 0, 0, 0);
+                    } else {
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bh, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh, acc[n], 0, 0, 0);
+                    }
+                }
             }
         }
 #pragma unroll
@@ -184,9 +200,9 @@ int main(int argc, char** argv) {
     hipMalloc(&res, (size_t)n_wg * 128 * ld * 4);
     hipMemset(res, 0, (size_t)n_wg * 128 * ld * 4);
     hipMalloc(&clk, n_wg * 16);
-    const char* names[5] = {"32x32x16 wave 32x256", "16x16x32 wave 32x256", "32x32x16 wave 64x128", "16x16x32 wave 64x128", "32x32x16 64x128 no LDS reads"};
+    const char* names[7] = {"32x32x16 wave 32x256", "16x16x32 wave 32x256", "32x32x16 wave 64x128", "16x16x32 wave 64x128", "32x32x16 64x128 no LDS reads", "32x32x16 32x256 order lo.hi hi.hi hi.lo", "32x32x16 32x256 order alternating"};
     for (int e = 0; e < 2; ++e)
-        for (int shape = 0; shape < (e ? 2 : 5); ++shape) {
+        for (int shape = 0; shape < (e ? 2 : 7); ++shape) {
             hipEvent_t e0, e1;
             hipEventCreate(&e0);
             hipEventCreate(&e1);
@@ -195,6 +211,8 @@ int main(int argc, char** argv) {
                 else if (shape == 1) hipLaunchKernelGGL(probe<1>, dim3(n_wg), dim3(256), 32768, 0, frag, steps16, y, res, ld, e, clk);
                 else if (shape == 2) hipLaunchKernelGGL(probe<2>, dim3(n_wg), dim3(256), 32768, 0, frag, steps16, y, res, ld, e, clk);
                 else if (shape == 3) hipLaunchKernelGGL(probe<3>, dim3(n_wg), dim3(256), 32768, 0, frag, steps16, y, res, ld, e, clk);
+                else if (shape == 5) hipLaunchKernelGGL(probe<5>, dim3(n_wg), dim3(256), 32768, 0, frag, steps16, y, res, ld, e, clk);
+                else if (shape == 6) hipLaunchKernelGGL(probe<6>, dim3(n_wg), dim3(256), 32768, 0, frag, steps16, y, res, ld, e, clk);
                 else hipLaunchKernelGGL(probe<4>, dim3(n_wg), dim3(256), 32768, 0, frag, steps16, y, res, ld, e, clk);
             };
             for (int i = 0; i < 20; ++i) launch();  // ~ 50 ms of load first: the clock settles
