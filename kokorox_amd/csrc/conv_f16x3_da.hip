@@ -19,7 +19,12 @@
 // left is ONE barrier per 16-channel chunk (the input images alternate between two LDS buffers).
 // B fragments: a three-entry ring over the column tiles; a tile's three MFMAs run back to back on its accumulator and the
 // fragments of the tile two further on are read under them.
-// Two forms of the main loop:
+// Three forms of the main loop:
+//   * W2 (the 256-column tile's compile-time tap counts, default): the four waves as 2 x 2, each 64 rows x 128 columns, so that a
+//     B fragment read feeds six MFMAs instead of three and the MFMAs of a tile alternate between two accumulators; two ring
+//     slots of 16 registers, every vector load unconditional and every wait a compile-time constant (see "W2 form" below;
+//     profiles/r03_w2_form.txt).  Bit-identical to the 4 x 1 forms below, which remain for the 128-column tile (small grids),
+//     the reduced-precision mode and KX_DA_W2=0;
 //   * compile-time tap count (KT = 3, 7, 11: the resblock convs, 85 % of the conv time): a chunk's KT steps are unrolled and
 //     the NEXT chunk's input transform (AdaIN affine + snake + f16 split, ~600 vector instructions per wave and chunk) is
 //     dealt out in 24 pieces between the MFMAs of the chunk's column tiles, where the matrix pipe hides it; done in one
@@ -45,7 +50,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-#ifndef KX_DA_P1
+#if !defined(KX_DA_P1) && !defined(KX_DA_W2)
 bool conv16_da_eligible(int BM, int K, int dil, int stride, int merged) {
     return BM == 128 && stride == 1 && !merged && (K - 1) * dil + 256 <= 384;
 }
@@ -58,8 +63,10 @@ bool conv16_use_da(int BM, int K, int dil, int stride, int merged) {
 // P1: the opt-in reduced-precision form (KOKOROX_CONV=f16, BASELINE configs[2] "bf16" / the reference's model_fp16
 // variants, hf_cache.rs:135-144): ONE v_mfma_f32_32x32x16_f16 per product on the high halves only (weights and activations
 // rounded to f16, f32 accumulation); the low halves are neither loaded, nor computed, nor read.
-template <int ACT, int KT, int NTT, bool P1>
+// W2: the unrolled main loop with the four waves as 2 x 2 (64 rows x 128 columns each), see "W2 form" below.
+template <int ACT, int KT, int NTT, bool P1, bool W2 = false>
 __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(const ConvArgs a) {
+    static_assert(!W2 || (KT >= 3 && (KT & 1) && NTT == 8), "W2: odd compile-time tap counts on the 256-column tile");
     // NTT = 8: the 128 x 256 tile of chip-filling launches; NTT = 4: 128 x 128 for small grids (batch 1), three workgroups per CU
     constexpr int BM = 128, NT = NTT, BN = 32 * NT;
     // Staged window.  Run-time tap count: BN + 128 columns = NJF 64-column blocks per wave pair, 8 channels each.
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     const int up2 = a.in_up2;
     const int Lsrc = up2 ? ((Lin + 1) >> 1) : Lin;
 
-    f32x16 acc[1][NT];
+    f32x16 acc[1][NT];  // (W2: tiles 0 .. NT/2 - 1 = row block 0, the rest = row block 1 of the wave's 64 x 128)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     // still-empty registers elsewhere BEFORE the wait: stale fragments whenever the memory system was slow), a scheduling
     // barrier follows it, and only then does an empty asm hand the fragments on as new values: any copy the allocator
     // wants is made from that point, after the data has landed.
-    auto wait_A = [&](int age, u32x4& a_hi, u32x4& a_lo) __attribute__((always_inline)) {
+    auto wait_vm = [&](int age) __attribute__((always_inline)) {
         if (age >= 60) asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
         else if (age >= 34) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
         else if (age >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
@@ -375,9 +382,34 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         else if (age >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (age >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto wait_A = [&](int age, u32x4& a_hi, u32x4& a_lo) __attribute__((always_inline)) {
+        wait_vm(age);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (P1) asm volatile("" : "+v"(a_hi));
         else asm volatile("" : "+v"(a_hi), "+v"(a_lo));
+    };
+    // W2: wave (wr, wc) = (wave >> 1, wave & 1) owns rows [64 wr, 64 wr + 64) and columns [128 wc, 128 wc + 128): a ring slot
+    // holds the fragments of a step for its TWO 32-row blocks (the same packed image, rows 64 wr + 32 i + r).
+    const int wr2 = wave >> 1, wc2 = wave & 1;
+    const uint4* wlane2 = reinterpret_cast<const uint4*>(a.w16) + (long)ct * n_steps * tap_units + h * BM + wr2 * 64 + r;
+    constexpr int APL2 = P1 ? 2 : 4;  // vector loads per refill of a W2 slot
+    auto load_A2 = [&](int s, u32x4 (&xh)[2], u32x4 (&xl)[2]) __attribute__((always_inline)) {
+        // (unconditional, so that the waits of the W2 loop are compile-time constants: a step past the end re-reads the last one,
+        // and the loop's exit keeps the registers reserved until the final wait)
+        const uint4* p = wlane2 + (long)(s < n_steps ? s : n_steps - 1) * tap_units;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xh[0]) : "v"(p) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(xh[1]) : "v"(p) : "memory");
+        if constexpr (!P1) {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xl[0]) : "v"(p + 2 * BM) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(xl[1]) : "v"(p + 2 * BM) : "memory");
+        }
+    };
+    auto wait_A2 = [&](int age, u32x4 (&xh)[2], u32x4 (&xl)[2]) __attribute__((always_inline)) {
+        wait_vm(age);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (P1) asm volatile("" : "+v"(xh[0]), "+v"(xh[1]));
+        else asm volatile("" : "+v"(xh[0]), "+v"(xh[1]), "+v"(xl[0]), "+v"(xl[1]));
     };
     // vector loads of one load_raw(): exact counting is worth 2 % of the step against counting the asm loads only (always
     // a safe under-estimate: 123.8 vs 126.2 ms)
@@ -392,7 +424,10 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         cyc0 = __builtin_readcyclecounter();
     }
 #endif
-    u32x4 ah0, al0 = {0, 0, 0, 0}, ah1, al1 = {0, 0, 0, 0}, ah2, al2 = {0, 0, 0, 0};
+    u32x4 ah0 = {0, 0, 0, 0}, al0 = {0, 0, 0, 0}, ah1 = {0, 0, 0, 0}, al1 = {0, 0, 0, 0}, ah2 = {0, 0, 0, 0}, al2 = {0, 0, 0, 0};
+    u32x4 a2h[2][2] = {}, a2l[2][2] = {};  // W2: [slot][row block]
+    if constexpr (W2) load_A2(0, a2h[1], a2l[1]);  // (a chunk's first step arrives in slot 1, see below)
+    if constexpr (!W2) {
     load_A(0, ah0, al0);
     load_A(1, ah1, al1);
     // (a slot that is never consumed must never be loaded: its asm result is dead to the compiler, which hands the registers
@@ -401,6 +436,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     // form -- 2.69 / 1.96 ms against 2.66 / 1.90 -- and is not built.)
     if constexpr (KT == 0 || KT >= 3) load_A(2, ah2, al2);
     else ah2 = al2 = u32x4{0, 0, 0, 0};
+    }
 
     load_raw(0);
     stage_from_raw(Xs, 0);
@@ -415,7 +451,122 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         age0 = age1 = age2 = raw_ops;
     }
 
-    if constexpr (KT > 0) {
+    if constexpr (W2) {
+        // ================= W2 form: the unrolled loop with the waves as 2 x 2 ===================================
+        // Why (profiles/r03_mfma_shape_probe.txt): the chip is power-limited under this kernel and the LDS operand reads are 7 % of
+        // a bare MFMA loop's time; with 64 x 128 wave tiles a B fragment feeds six MFMAs instead of three (-4.8 % there), and the
+        // MFMAs of a tile alternate between two accumulators instead of queueing on one.  The price is 16 A registers per ring
+        // slot instead of 8 -- paid by a TWO-slot ring: a refill one step (24 MFMAs ~ 1 us) ahead is enough (the four-slot ring
+        // of the form below cut to two measured 0.8 % FASTER, profiles/r03_w2_form.txt).
+        // Tap t of a chunk sits in slot t & 1 and is refilled behind its last tile with tap t + 2.  KT is odd, so the next
+        // chunk's tap 0 lands in slot 1: it does, and is moved to slot 0 at the chunk's start (16 v_mov, after its wait), so that
+        // the slots stay static in the unrolled code.  Every vector-memory operation of the loop is unconditional (indices past
+        // the end are clamped), so the age of a slot at its wait is a compile-time constant: the other slot's refill, or -- tap 0
+        // -- the input prefetch batch issued at the chunk boundary.
+        // Per accumulator the products are added in the order of every other form: results are bit-identical to them.
+        constexpr int NW = NT / 2;          // column tiles of a wave
+        constexpr int TILES = KT * NW;      // tiles per chunk, six MFMAs each (P1: two)
+        constexpr int MPT = P1 ? 2 : 6;
+        int cur = 0;
+#ifndef KX_W2_BR
+#define KX_W2_BR 2
+#endif
+        constexpr int BR = KX_W2_BR;  // B-fragment ring: tile i in entry i % BR, read BR - 1 tiles ahead
+        half8 fh[BR], fl[BR];
+        auto load_tile = [&](int t, int n, half8& fhx, half8& flx) __attribute__((always_inline)) {
+            const uint4* xt = Xs + cur * XBUF + h * XWp + r + t * dil + wc2 * 128 + n * 32;
+            fhx = *reinterpret_cast<const half8*>(xt);
+            if constexpr (!P1) flx = *reinterpret_cast<const half8*>(xt + 2 * XWp);
+        };
+#ifndef KX_W2_I0_LONG
+#define KX_W2_I0_LONG 5  // steps before the first transform part, k >= 9 (the input prefetch was issued at the chunk's start)
+#endif
+#ifndef KX_W2_I0_MID
+#define KX_W2_I0_MID 2   // k = 5 .. 8 (3: +1.1 .. 1.7 % on the k = 7 launches)
+#endif
+#ifndef KX_W2_I0_SHORT
+#define KX_W2_I0_SHORT 1  // k < 5
+#endif
+        constexpr int I0 = (KT >= 9 ? KX_W2_I0_LONG : (KT >= 5 ? KX_W2_I0_MID : KX_W2_I0_SHORT)) * NW;
+#ifndef KX_W2_G
+#define KX_W2_G 2
+#endif
+        constexpr int G = (P1 || KT < 5) ? 1 : KX_W2_G;  // tiles per scheduling region
+        static_assert(NW % G == 0 && I0 < TILES, "W2: regions inside a step, tiles left for the transform");
+        static_assert(TILES % BR == 0, "W2: a chunk's first tile always sits in ring entry 0");
+        static_assert(BR - 1 <= NW, "W2: the ring's head start lies inside the first step");
+        static_for<0, BR - 1>([&](auto qc) __attribute__((always_inline)) { load_tile(0, decltype(qc)::value, fh[decltype(qc)::value], fl[decltype(qc)::value]); });
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const int s0 = ch * KT;
+            static_for<0, TILES>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int t = i / NW, n = i % NW, sl = t & 1, e = i % BR, ip = i + BR - 1, e2 = ip % BR;
+                if constexpr (n == 0 && t == 0) {
+                    wait_A2(raw_ops, a2h[1], a2l[1]);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        a2h[0][q] = a2h[1][q];
+                        a2l[0][q] = a2l[1][q];
+                    }
+                    load_A2(s0 + 1, a2h[1], a2l[1]);
+                } else if constexpr (n == 0) {
+                    wait_A2(APL2, a2h[sl], a2l[sl]);
+                }
+                const half8 a0h = __builtin_bit_cast(half8, a2h[sl][0]), a1h = __builtin_bit_cast(half8, a2h[sl][1]);
+                const half8 a0l = __builtin_bit_cast(half8, a2l[sl][0]), a1l = __builtin_bit_cast(half8, a2l[sl][1]);
+                if constexpr (ip < TILES) load_tile(ip / NW, ip % NW, fh[e2], fl[e2]);
+                if constexpr (i % G == 0) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!P1) {
+                    acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, fh[e], acc[0][n], 0, 0, 0);
+                    acc[0][NW + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, fh[e], acc[0][NW + n], 0, 0, 0);
+                    acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, fl[e], acc[0][n], 0, 0, 0);
+                    acc[0][NW + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, fl[e], acc[0][NW + n], 0, 0, 0);
+                }
+                acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, fh[e], acc[0][n], 0, 0, 0);
+                acc[0][NW + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, fh[e], acc[0][NW + n], 0, 0, 0);
+                // half-units [h0, h1) of the next chunk's transform ride on this tile (in the last chunk: stale registers into an
+                // image nobody reads)
+                constexpr int h0 = i > I0 ? ((i - I0) * HU) / (TILES - I0) : 0;
+                constexpr int h1 = i + 1 > I0 ? ((i + 1 - I0) * HU) / (TILES - I0) : 0;
+                static_assert(h1 - h0 <= 4, "at most four half-units per tile");
+                static_for<h0, h1>([&](auto hc) __attribute__((always_inline)) {
+                    constexpr int hh = decltype(hc)::value;
+                    xform_a(hh / 2, hh & 1, ch + 1);
+                    xform_b();
+                    xform_c(hh / 2, hh & 1, Xs + (cur ^ 1) * XBUF, ch + 1);
+                });
+                if constexpr (i % G == G - 1) {  // the pipeline of the region: its half-units spread over its MFMAs
+                    constexpr int ig = i - (G - 1);
+                    constexpr int hg0 = ig > I0 ? ((ig - I0) * HU) / (TILES - I0) : 0;
+                    constexpr int nh = h1 - hg0;
+                    constexpr int per = nh > 0 ? (nh * 27 + MPT * G - 1) / (MPT * G) : 0;
+#pragma unroll
+                    for (int tg = 0; tg < G; ++tg) {
+                        if (tg > 0) __builtin_amdgcn_sched_group_barrier(0x100, P1 ? 1 : 2, 0);
+#pragma unroll
+                        for (int k6 = 0; k6 < MPT; ++k6) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            if (per > 0) __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (n == NW - 1) {  // refill the slot with the step two further on
+                    if constexpr (t + 2 <= KT - 1) load_A2(s0 + t + 2, a2h[sl], a2l[sl]);
+                    else if constexpr (t == KT - 2) load_A2(s0 + KT, a2h[1], a2l[1]);  // (slot 1: the next chunk's tap 0)
+                }
+            });
+            // (the barrier and what follows run after the last chunk too: one barrier and one prefetch batch nobody reads, for a
+            // loop without a run-time condition in it)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            cur ^= 1;
+            load_raw(ch + 2 < n_chunks ? ch + 2 : n_chunks - 1);
+            static_for<0, BR - 1>([&](auto qc) __attribute__((always_inline)) { load_tile(0, decltype(qc)::value, fh[decltype(qc)::value], fl[decltype(qc)::value]); });
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (P1) asm volatile("" ::"v"(a2h[1][0]), "v"(a2h[1][1]));  // (the last refill: reserved until here)
+        else asm volatile("" ::"v"(a2h[1][0]), "v"(a2h[1][1]), "v"(a2l[1][0]), "v"(a2l[1][1]));
+    } else if constexpr (KT > 0) {
         // ================= compile-time tap count (the resblock convs: k = 3, 7, 11) ============================
         // A chunk's KT steps are unrolled, so every ring slot and every transform part has a fixed place in the code:
         // the NEXT chunk's transform (24 half-units of ~25 vector instructions) is dealt out over the chunk's 8 KT column
@@ -675,7 +826,12 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     float2* stat_scr = reinterpret_cast<float2*>(smem16) + wave * (32 * 33);
     float* wide_scr = reinterpret_cast<float*>(stat_scr);  // (the wide store's 4 KiB transpose scratch, same per-wave region)
     // 128-column groups of four column tiles = the statistics groups of the other tile shapes
-    if constexpr (NT == 8) {
+    if constexpr (W2) {
+        conv_store_group<EPI_ROWS>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][0]), a.w_unscale, b, ct * BM + wr2 * 64, t0 + 128 * wc2, r,
+                                   h, ncols, Lout, tile_x * 2 + wc2, stat_scr, wide_scr);
+        conv_store_group<EPI_ROWS>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][4]), a.w_unscale, b, ct * BM + wr2 * 64 + 32, t0 + 128 * wc2,
+                                   r, h, ncols, Lout, tile_x * 2 + wc2, stat_scr, wide_scr);
+    } else if constexpr (NT == 8) {
         conv_store_group<EPI_ROWS>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][0]), a.w_unscale, b, ct * BM + wave * 32, t0, r, h,
                                    ncols, Lout, tile_x * 2, stat_scr, wide_scr);
         conv_store_group<EPI_ROWS>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][4]), a.w_unscale, b, ct * BM + wave * 32, t0 + 128, r,
@@ -706,9 +862,15 @@ constexpr bool DA_P1 = true;
 constexpr bool DA_P1 = false;
 #endif
 
+#ifdef KX_DA_W2
+constexpr bool DA_W2 = true;
+#else
+constexpr bool DA_W2 = false;
+#endif
+
 template <int ACT, int KT, int NTT>
 static void launch_da_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
-    auto kern = conv1d_f16x3_da_kernel<ACT, KT, NTT, DA_P1>;
+    auto kern = conv1d_f16x3_da_kernel<ACT, KT, NTT, DA_P1, DA_W2>;
     constexpr int BN = 32 * NTT;
     // two input buffers (48 / 32 KiB), and never less than the statistics scratch of the epilogue (4 waves x 8.25 KiB)
     constexpr size_t lds_x = 16 * (size_t)2 * 4 * (BN + 128), lds_scr = 4 * 32 * 33 * sizeof(float2);
@@ -718,6 +880,27 @@ static void launch_da_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     KX_HIP(hipGetLastError());
 }
+
+#ifdef KX_DA_W2
+// The W2 forms (conv_f16x3_da_w2.hip defines KX_DA_W2 and includes this file): the unrolled forms of the 256-column tile;
+// launch_da_ntt<8> of the main translation unit forwards here.  Results are bit-identical to the forms they replace.
+// (The reduced-precision mode keeps the 4 x 1 layout: its W2 instantiations measured 78.2 against 78.4 ms per step -- that mode is
+// bound by the transform's vector work, not by the operand reads -- and are not built.)
+bool conv16_da_w2_has(int act, int K) { return (act == ACT_SNAKE && (K == 3 || K == 7 || K == 11)) || (act == ACT_LEAKY && K == 3); }
+void launch_conv1d_f16x3_da_w2(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
+    KX_REQUIRE(conv16_da_w2_has(a.act, a.K) && (a.K - 1) * a.dil <= 64 && !a.prec1, "conv1d f16x3 da w2: launch not eligible");
+#ifdef KX_DA_AUDIT
+    launch_da_inst<ACT_SNAKE, 11, 8>(a, B, max_cols, s);
+    return;
+#endif
+    if (a.act == ACT_LEAKY) launch_da_inst<ACT_LEAKY, 3, 8>(a, B, max_cols, s);
+    else if (a.K == 11) launch_da_inst<ACT_SNAKE, 11, 8>(a, B, max_cols, s);
+    else if (a.K == 7) launch_da_inst<ACT_SNAKE, 7, 8>(a, B, max_cols, s);
+    else launch_da_inst<ACT_SNAKE, 3, 8>(a, B, max_cols, s);
+}
+#else
+bool conv16_da_w2_has(int act, int K);                                                          // conv_f16x3_da_w2.hip
+void launch_conv1d_f16x3_da_w2(const ConvArgs& a, int B, int max_cols, hipStream_t s);  // conv_f16x3_da_w2.hip
 
 template <int NTT>
 static void launch_da_ntt(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
@@ -730,6 +913,14 @@ static void launch_da_ntt(const ConvArgs& a, int B, int max_cols, hipStream_t s)
     static const int st = getenv("KX_DA_STATIC") ? atoi(getenv("KX_DA_STATIC")) : 1;
     // (the unrolled forms stage a window of BN + 64 columns: (K - 1) dil <= 64, true of every resblock conv of the graph)
     const bool w64 = (a.K - 1) * a.dil <= 64;
+#ifndef KX_DA_P1
+    // the 256-column tile's unrolled forms: the 2 x 2 wave layout (KX_DA_W2=0: 4 x 1; bit-identical either way)
+    static const int w2 = getenv("KX_DA_W2") ? atoi(getenv("KX_DA_W2")) : 1;
+    if (w2 && st && w64 && NTT == 8 && conv16_da_w2_has(a.act, a.K)) {
+        launch_conv1d_f16x3_da_w2(a, B, max_cols, s);
+        return;
+    }
+#endif
     if (a.act == ACT_SNAKE) {
         if (st && w64 && a.K == 11) launch_da_inst<ACT_SNAKE, 11, NTT>(a, B, max_cols, s);
         else if (st && w64 && a.K == 7) launch_da_inst<ACT_SNAKE, 7, NTT>(a, B, max_cols, s);
@@ -742,7 +933,10 @@ static void launch_da_ntt(const ConvArgs& a, int B, int max_cols, hipStream_t s)
         launch_da_inst<ACT_NONE, 0, NTT>(a, B, max_cols, s);
 }
 
-#ifdef KX_DA_P1
+#endif  // KX_DA_W2
+
+#if defined(KX_DA_W2)
+#elif defined(KX_DA_P1)
 // bn: 256 or 128, as launch_conv1d_f16x3_da (which forwards here when a.prec1 is set)
 void launch_conv1d_f16x3_da_p1(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn) {
     if (bn == 256)

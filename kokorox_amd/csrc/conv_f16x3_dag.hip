@@ -389,13 +389,15 @@ void launch_conv1d_f16x3_dag(const ConvArgs& a, int B, int max_cols, hipStream_t
     KX_REQUIRE(a.n_chunks16 == (a.Cin + CK16 - 1) / CK16 && a.w16 != nullptr, "conv1d f16x3 dag: weights not packed");
     KX_REQUIRE(a.pad == 0, "conv1d f16x3 dag: a 1-tap GEMM has no padding");
     if (max_cols <= 0) return;
-    // fewer 128 x 128 tiles than CUs: the narrow form (KX_DAGN=0: never; results are bit-identical either way)
+    // at most half as many 128 x 128 tiles as CUs: the narrow form (KX_DAGN=0: never, 2: always; results are bit-identical either
+    // way).  Measured by batch, off / on: 1: 11.85 / 10.55 ms, 4: 16.74 / 15.73, 16: 36.6 / 36.5; at 32 and 64 no launch qualifies
+    // (forced everywhere it costs 3 - 5 %: four times the weight traffic and the split repeated by four waves).
     static const int narrow = getenv("KX_DAGN") ? atoi(getenv("KX_DAGN")) : 1;
     const long wgs = (long)((max_cols + 127) / 128) * ((a.Cout + 127) / 128) * (a.merge_T > 0 ? 1 : B);
     // (the narrow form: whole chunks only, and 32-bit byte offsets into the input)
     const long x_span = ((long)a.x_bs * (a.merge_T > 0 ? a.merge_B : B) + (long)CK16 * a.x_ld) * 4;
     const bool narrow_ok = a.Cin % CK16 == 0 && x_span < (1L << 31);
-    if (narrow_ok && (narrow == 2 || (narrow && wgs < conv16_cu_count()))) {
+    if (narrow_ok && (narrow == 2 || (narrow && 2 * wgs <= conv16_cu_count()))) {
         if (a.act == ACT_LEAKY)
             launch_dagn_inst<ACT_LEAKY>(a, B, max_cols, s);
         else

@@ -110,11 +110,12 @@ def _prefetch_batches(lines):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
-@pytest.mark.parametrize("src", ["conv_f16x3_da.hip", "conv_f16x3_da_p1.hip"])  # f16x3 and reduced-precision instantiations
+@pytest.mark.parametrize("src", ["conv_f16x3_da.hip", "conv_f16x3_da_p1.hip", "conv_f16x3_da_w2.hip"])  # f16x3, reduced precision, 2 x 2 waves
 def test_direct_a_conv_assembly(tmp_path, src):
     ks = _kernels(_asm(src, tmp_path, "-DKX_DA_AUDIT"))
     assert ks, "no kernel found"
-    assert len(ks) == 14, sorted(ks)  # every instantiation launch_da_ntt can select, both tile widths
+    # every instantiation launch_da_ntt can select, both tile widths; the four unrolled 256-column forms of the 2 x 2 layout
+    assert len(ks) == (4 if src == "conv_f16x3_da_w2.hip" else 14), sorted(ks)
     for name, lines in ks.items():
         assert not any("scratch_" in ln for ln in lines), f"{name} spills"
         bad = _audit_no_touch_before_wait(lines)
@@ -130,7 +131,7 @@ def test_direct_a_conv_assembly(tmp_path, src):
         # instruction budget of the unrolled main loops (text between the first and the last MFMA of the chunk body): vector
         # instructions per MFMA.  The matrix pipe hides ~5 issue slots per 32-cycle MFMA (MI355X_MICROARCH.md); the k = 11
         # form must stay well inside that, and none of the forms may quietly grow (round 3: 2.1 / 3.3 / 7.3 at 256 columns)
-        if kt > 0 and src == "conv_f16x3_da.hip":
+        if kt > 0 and src != "conv_f16x3_da_p1.hip":
             mf = [i for i, ln in enumerate(lines) if "v_mfma" in ln]
             body = lines[mf[0]:mf[-1] + 1]
             valu = sum(1 for ln in body if re.match(r"\s*v_(?!mfma)", ln))
