@@ -317,6 +317,35 @@ def test_direct_a_kernel_is_bit_identical_under_load(B, Cin, Cout, L, k, d):
 
 
 @pytest.mark.gpu
+def test_direct_a_4x1_layout_of_the_256_column_tile_is_still_bit_identical():
+    """The 256-column tile's unrolled forms default to the 2 x 2 wave layout (conv_f16x3_da_w2.hip), which the test above
+    exercises; the 4 x 1 forms stay in the library (KX_DA_W2=0, read once per process, hence the child process) as the A/B
+    reference and must keep producing the same bits: mode 3 against the LDS-DMA kernel (mode 2) for 7 and 11 taps."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np\n"
+        "from kokorox_amd import hip_koko as hk\n"
+        "rng = np.random.default_rng(3)\n"
+        "for (B, C, L, k, d) in ((4, 128, 16000, 11, 3), (4, 256, 5000, 7, 1)):\n"
+        "    x = rng.standard_normal((B, C, L), dtype=np.float32)\n"
+        "    w = (rng.standard_normal((C, C, k), dtype=np.float32) / np.sqrt(C * k)).astype(np.float32)\n"
+        "    b = rng.standard_normal(C, dtype=np.float32)\n"
+        "    alpha = (0.5 + rng.random(C)).astype(np.float32)\n"
+        "    norm = rng.standard_normal((B, 3, C), dtype=np.float32)\n"
+        "    kw = dict(pad=d * (k - 1) // 2, dil=d, act=2, alpha=alpha, norm=norm)\n"
+        "    y2 = hk.conv1d(x, w, b, mode=2, **kw)\n"
+        "    y3 = hk.conv1d(x, w, b, mode=3, **kw)\n"
+        "    assert np.isfinite(y3).all() and np.array_equal(y2, y3), (k, float(np.abs(y2 - y3).max()))\n"
+        "print('same bits')\n")
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, KX_DA_W2="0"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "same bits" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_direct_a_run_time_tap_forms_are_bit_identical_under_load():
     """The forms of the direct-A kernel that the resblock test above does not reach, on chip-filling launches, against the
     LDS-DMA kernel: (a) a polyphase transposed conv (run-time tap count, two taps, scatter store), (b) a one-tap conv with
