@@ -73,8 +73,22 @@ __global__ __launch_bounds__(256, 2) void probe(const uint4* src, int steps, flo
 #pragma unroll
     for (int i = 0; i < 4; ++i) pv[i] = f32x2{v[2 * i], v[2 * i + 1]};
     const unsigned long long c0 = __builtin_readcyclecounter();
+    using f32x4p = __attribute__((ext_vector_type(4))) float;
+    f32x4p acc4[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc4[j] = f32x4p{0.f, 0.f, 0.f, 0.f};
     XState xs{v[0], v[1], v[2], v[3], v[4], v[5], v[6], 0u, 0u, v[7], (unsigned)(tid * 4)};
     for (int s = 0; s < steps; ++s) {
+        if constexpr (KIND == 11) {  // the same transform stream beside the same FLOPs issued as v_mfma_f32_16x16x32_f16 (two per slot)
+            sfor<0, 24>([&](auto ic) {
+                constexpr int idx = decltype(ic)::value;
+                constexpr int blk = 4 * (idx / 3) + 2 * (idx & 1);
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc4[blk]) : "v"(a), "v"(b));
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc4[blk + 1]) : "v"(a), "v"(b));
+                sfor<0, NV>([&](auto qc) { xop<(idx * NV + decltype(qc)::value) % 54>(xs); });
+            });
+            continue;
+        }
         if constexpr (KIND == 10) {  // the conv's transform, NV of its instructions behind every MFMA, in program order
             sfor<0, 24>([&](auto ic) {
                 constexpr int idx = decltype(ic)::value;
@@ -129,6 +143,10 @@ __global__ __launch_bounds__(256, 2) void probe(const uint4* src, int steps, flo
 #pragma unroll
     for (int i = 0; i < 8; ++i) t += v[i];
     t += xs.x + xs.y0 + xs.y1 + (float)xs.hp + (float)xs.lp;
+    if constexpr (KIND == 11) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) t += acc4[j][0] + acc4[j][1] + acc4[j][2] + acc4[j][3];
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) t += pv[i][0] + pv[i][1];
     if (t == 123.456f) sink[0] = t;
@@ -154,8 +172,8 @@ static void run(const uint4* src, int steps, float* sink, unsigned long long* cy
     double s = 0;
     for (auto x : h) s += (double)x;
     const double per = s / n_wg / ((double)steps * 24);
-    const char* kinds[11] = {"independent v_fma", "ONE dependent v_fma chain", "v_readlane + v_mul with that SGPR (pairs)", "v_cvt_pk_f16_f32 + v_cvt_f32_f16 (pairs)", "ds_write_b32",
-                             "independent v_pk_fma_f32", "ONE dependent v_pk_fma_f32 chain", "TWO interleaved dependent v_fma chains", "FOUR interleaved dependent v_fma chains", "TWO interleaved dependent v_pk_fma_f32 chains", "the conv transform's own instruction sequence"};
+    const char* kinds[12] = {"independent v_fma", "ONE dependent v_fma chain", "v_readlane + v_mul with that SGPR (pairs)", "v_cvt_pk_f16_f32 + v_cvt_f32_f16 (pairs)", "ds_write_b32",
+                             "independent v_pk_fma_f32", "ONE dependent v_pk_fma_f32 chain", "TWO interleaved dependent v_fma chains", "FOUR interleaved dependent v_fma chains", "TWO interleaved dependent v_pk_fma_f32 chains", "the conv transform's own instruction sequence", "that sequence beside 2 x v_mfma_f32_16x16x32_f16 per slot"};
     printf("%s accumulators, %d x [%s] per MFMA: %.1f ticks per MFMA and wave; %d workgroups %.3f ms %.0f TFLOP/s issued\n", AGPR ? "AccVGPR " : "ArchVGPR", NV, kinds[KIND], per, n_wg, ms, tflops);
 }
 
@@ -207,5 +225,14 @@ int main() {
     run<4, false, 10>(src, steps, sink, cyc, n_wg);
     run<6, false, 10>(src, steps, sink, cyc, n_wg);
     run<9, false, 10>(src, steps, sink, cyc, n_wg);
+    // long launches (the short ones carry a few % of noise): 32x32x16 against 16x16x32 with the transform stream of k = 11 / 7 / 3
+    run<0, false, 10>(src, steps * 8, sink, cyc, n_wg);
+    run<0, false, 11>(src, steps * 8, sink, cyc, n_wg);
+    run<3, false, 10>(src, steps * 8, sink, cyc, n_wg);
+    run<3, false, 11>(src, steps * 8, sink, cyc, n_wg);
+    run<4, false, 10>(src, steps * 8, sink, cyc, n_wg);
+    run<4, false, 11>(src, steps * 8, sink, cyc, n_wg);
+    run<9, false, 10>(src, steps * 8, sink, cyc, n_wg);
+    run<9, false, 11>(src, steps * 8, sink, cyc, n_wg);
     return 0;
 }
