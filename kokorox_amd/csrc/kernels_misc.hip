@@ -1044,23 +1044,42 @@ __global__ void istft_spec_kernel(const float* cp, long bs, int ld, float* spec,
 }
 __global__ void istft_ola_kernel(const float* spec, long bs, int ld, float* audio, long audio_ld, const int* frames,
                                  int variant) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    // the inverse-DFT rows are indexed by the sample's position in its frame, which differs from lane to lane: from constant
+    // memory that is one scalar load per distinct index (808 us per batch-64 launch); from LDS it is an ordinary banked read.
+    // The spectrum columns a block's 256 samples touch (57 frames x 22 rows) are staged in LDS too: every sample reads 88 of
+    // them, five neighbouring samples the same ones (407 -> ~100 us).
+    constexpr int FW = 60;  // frames staged per block: samples j0 .. j0 + 255 touch frames (j0 - 5) / 5 .. (j0 + 265) / 5
+    __shared__ float s_re[20][11], s_im[20][11], s_wsq[20];
+    __shared__ float s_sp[22][FW];
+    const int b = blockIdx.y, j0 = blockIdx.x * blockDim.x;
     const int nf = 120 * frames[b] + 1;
+    if (j0 >= 600 * frames[b]) return;  // (block-uniform)
+    for (int i = threadIdx.x; i < 220; i += blockDim.x) {
+        s_re[i / 11][i % 11] = c_inv_re[variant][i / 11][i % 11];
+        s_im[i / 11][i % 11] = c_inv_im[variant][i / 11][i % 11];
+    }
+    if (threadIdx.x < 20) s_wsq[threadIdx.x] = c_win_sq[threadIdx.x];
+    const int f0 = j0 >= 9 ? (j0 - 5) / 5 : 0;  // first frame any sample of the block reads (flo of its first sample)
+    const float* sp = spec + b * bs;
+    for (int i = threadIdx.x; i < 22 * FW; i += blockDim.x) {
+        const int k = i / FW, f = f0 + i % FW;
+        s_sp[k][i % FW] = f < nf ? sp[(long)k * ld + f] : 0.f;
+    }
+    __syncthreads();
+    const int j = j0 + threadIdx.x;
     if (j >= 600 * frames[b]) return;
     const int n = j + 10;
     int fhi = n / 5;
     if (fhi > nf - 1) fhi = nf - 1;
     const int flo = n >= 19 ? (n - 15) / 5 : 0;
     float y = 0.f, env = 0.f;
-    const float* sp = spec + b * bs;
     for (int f = fhi; f >= flo; --f) {
         const int m = n - 5 * f;
         float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 11; ++k)
-            acc += c_inv_re[variant][m][k] * sp[(long)k * ld + f] + c_inv_im[variant][m][k] * sp[(long)(11 + k) * ld + f];
+        for (int k = 0; k < 11; ++k) acc += s_re[m][k] * s_sp[k][f - f0] + s_im[m][k] * s_sp[11 + k][f - f0];
         y += acc;
-        env += c_win_sq[m];
+        env += s_wsq[m];
     }
     audio[b * audio_ld + j] = variant == 0 ? y : y / env;
 }
