@@ -9,10 +9,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libkokorox_hip.so")
-SOURCES = ["conv_mfma.hip", "conv_f16x3.hip", "conv_f16x3_da.hip", "conv_f16x3_da_p1.hip", "conv_f16x3_da_w2.hip", "conv_f16x3_dag.hip", "kernels_misc.hip", "model.hip", "api.hip", "dispatcher.hip"]
+SOURCES = ["conv_mfma.hip", "conv_f16x3.hip", "conv_f16x3_da.hip", "conv_f16x3_da_p1.hip", "conv_f16x3_da_w2.hip", "conv_f16x3_da_s16.hip", "conv_f16x3_dag.hip", "kernels_misc.hip", "model.hip", "api.hip", "dispatcher.hip"]
 HEADERS = ["kx_common.h", "model.h", "kx_handle.h", "conv_epilogue.h", "conv_f16x3_common.h", os.path.join("..", "..", "include", "kokorox_hip.h")]
 # sources that include another source (the reduced-precision direct-A instantiations): rebuilt when that one changes
-EXTRA_DEPS = {"conv_f16x3_da_p1.hip": ["conv_f16x3_da.hip"], "conv_f16x3_da_w2.hip": ["conv_f16x3_da.hip"]}
+EXTRA_DEPS = {"conv_f16x3_da_p1.hip": ["conv_f16x3_da.hip"], "conv_f16x3_da_w2.hip": ["conv_f16x3_da.hip"], "conv_f16x3_da_s16.hip": ["conv_f16x3_da.hip"]}
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-result"]
 
 

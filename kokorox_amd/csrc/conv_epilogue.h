@@ -266,11 +266,13 @@ __device__ __forceinline__ void conv_store_rmw(const ConvArgs& a, f32x16 (&acc)[
 // in-order memory queue.  Per element the arithmetic is that of conv_store_rmw, operation for operation (the stored values
 // are bit-identical); the InstanceNorm partial sums are added in another order (4 columns per lane, 8 lanes per row, DPP),
 // which both tile widths of the direct-A kernel share (batch invariance).
-template <int LOADS>
-__device__ __forceinline__ void conv_store_wide4(const ConvArgs& a, f32x16 (&acc)[1][4], float acc_scale, int b, int row0,
-                                                 int col0, int lane, int stat_slot, float* scr) {
+// SC: scatter(n) writes the wave's 32 x 32 tile n of the group into scr, element (row, column) at scr[row * P + column]
+// (P: pitch in floats, a multiple of 4) -- the only part that knows the MFMA's C/D layout.
+// GT: 32-column tiles of the group (4 = 128 columns; 2 = the 64-column groups of the S16 form)
+template <int LOADS, int P, class SC, int GT = 4>
+__device__ __forceinline__ void conv_store_wide4_t(const ConvArgs& a, SC&& scatter, float acc_scale, int b, int row0, int col0,
+                                                   int lane, int stat_slot, float* scr) {
     using f32x4 = __attribute__((ext_vector_type(4))) float;
-    const int r = lane & 31, h = lane >> 5;
     const int rr = lane >> 3, pc = lane & 7;  // store layout: row 8 i + rr of the wave's 32, 16-byte piece pc of a tile row
     const bool want_stats = a.stat_part != nullptr;
     const buf_rsrc ybuf = make_buf(a.y + (long)b * a.y_bs);
@@ -287,7 +289,7 @@ __device__ __forceinline__ void conv_store_wide4(const ConvArgs& a, f32x16 (&acc
     for (int i = 0; i < 4; ++i) bias4[i] = a.bias ? a.bias[row0 + 8 * i + rr] : 0.f;
     const float div_d = a.out_div, div_rd = 1.0f / a.out_div;
     constexpr int UT = LOADS == 2 ? 1 : 2;  // tiles per load unit
-    constexpr int NU = 4 / UT;
+    constexpr int NU = GT / UT;
     f32x4 rv[2][UT][4], yv[2][LOADS == 2 ? UT : 1][4];
     auto load_unit = [&](int u, f32x4 (&rvu)[UT][4], f32x4 (&yvu)[LOADS == 2 ? UT : 1][4]) {
 #pragma unroll
@@ -307,11 +309,10 @@ __device__ __forceinline__ void conv_store_wide4(const ConvArgs& a, f32x16 (&acc
 #pragma unroll
         for (int t = 0; t < UT; ++t) {
             const int n = u * UT + t;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) scr[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[0][n][e];
+            scatter(n);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(scr + (8 * i + rr) * 32 + 4 * pc);
+                f32x4 v = *reinterpret_cast<const f32x4*>(scr + (8 * i + rr) * P + 4 * pc);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float x = __builtin_fmaf(v[c], acc_scale, bias4[i]);
@@ -344,6 +345,19 @@ __device__ __forceinline__ void conv_store_wide4(const ConvArgs& a, f32x16 (&acc
                 a.stat_part[((long)b * a.Cout + row0 + 8 * i + rr) * a.stat_tiles + stat_slot] = make_float2(s, q);
         }
     }
+}
+
+template <int LOADS>
+__device__ __forceinline__ void conv_store_wide4(const ConvArgs& a, f32x16 (&acc)[1][4], float acc_scale, int b, int row0,
+                                                 int col0, int lane, int stat_slot, float* scr) {
+    const int r = lane & 31, h = lane >> 5;
+    conv_store_wide4_t<LOADS, 32>(
+        a,
+        [&](int n) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) scr[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[0][n][e];
+        },
+        acc_scale, b, row0, col0, lane, stat_slot, scr);
 }
 
 // Dispatcher of the direct-A kernels for one 32-row x 128-column group: the wide form where it applies (plain channel-major
@@ -492,6 +506,52 @@ __device__ __forceinline__ void conv_store_group(const ConvArgs& a, f32x16 (&acc
         }
     }
     conv_store_tile<1, 4, EB, false>(a, acc, acc_scale, b, row0, col0, r, h, ncols, Lout, stat_slot, stat_scr);
+}
+
+// ---- the same for accumulators of v_mfma_f32_16x16x32_f16 (conv1d_f16x3_da_kernel, S16 form): the wave's 32 rows x 128 columns
+// are 2 x 8 blocks of 16 x 16, lane l holding rows 4 (l >> 4) + q, column l & 15 of a block.  The wide form scatters them into the
+// same LDS transpose (pitch 36: the four row groups of one write land on different banks) and is otherwise the code above; the
+// general forms get the group re-laid into the 32 x 32 C/D layout through the same scratch first.
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+template <int EB, int NBT, int GT>
+__device__ __forceinline__ void conv_store_group16(const ConvArgs& a, f32x4v (&acc)[2][NBT], const int blk0, float acc_scale, int b,
+                                                   int row0, int col0, int lane, int ncols, int Lout, int stat_slot,
+                                                   float2* stat_scr, float* wide_scr) {
+    const bool full = row0 + 32 <= a.Cout && col0 + 32 * GT <= ncols;  // wave-uniform
+    const int c16 = lane & 15, rg = lane >> 4;
+    auto scatter = [&](int n) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wide_scr[(16 * i + 4 * rg + q) * 36 + 16 * jb + c16] = acc[i][blk0 + 2 * n + jb][q];
+    };
+    if (KX_EPI_WIDE && a.store == ST_NORMAL && full && a.merge_T == 0 && !(a.dbg & 16384)) {
+        const bool res = a.resid != nullptr, accum = a.accum != 0;
+        if (res && accum) {
+            conv_store_wide4_t<2, 36, decltype(scatter)&, GT>(a, scatter, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
+            return;
+        }
+        if (res && !accum) {
+            conv_store_wide4_t<1, 36, decltype(scatter)&, GT>(a, scatter, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
+            return;
+        }
+        if (!res && !accum) {
+            conv_store_wide4_t<0, 36, decltype(scatter)&, GT>(a, scatter, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
+            return;
+        }
+    }
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 g[1][GT];
+#pragma unroll
+    for (int n = 0; n < GT; ++n) {
+        scatter(n);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) g[0][n][e] = wide_scr[((e & 3) + 8 * (e >> 2) + 4 * h) * 36 + r];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the scratch is the statistics scratch of the general form)
+    conv_store_tile<1, GT, EB, false>(a, g, acc_scale, b, row0, col0, r, h, ncols, Lout, stat_slot, stat_scr);
 }
 
 }  // namespace kx

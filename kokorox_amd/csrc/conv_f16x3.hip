@@ -449,8 +449,16 @@ static void launch_inst16(const ConvArgs& a, int B, int max_cols, hipStream_t s)
 // stats: the launch fuses InstanceNorm partial sums into its epilogue.  Their slots must then be 128 columns wide whatever the
 // launch geometry (an utterance's sums are added in the same order alone and beside a longer one: batch invariance), so the
 // 2 x 2-wave tile of short sequences (64-column slots) is not taken.
-void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int stride, int* bn, int* wn, int ws_force, bool stats) {
+void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int stride, int* bn, int* wn, int ws_force, bool stats,
+                      int act, int n_chunks16, bool prec1) {
     static const int force = env_int("KX_BN", 0);
+    if (ws_force != 1 && act >= 0 && conv16_da_s16_shape(BM, K, dil, stride, act, n_chunks16, false, prec1)) {
+        // the S16 form of the direct-A conv: 192 columns on chip-filling grids, 128 on small ones; three / two 64-column slots
+        const bool small = (long)((max_cols + 255) / 256) * ((Cout + 127) / 128) * B < 256 && ws_force != 2;
+        *bn = small ? 128 : 192;
+        *wn = small ? 2 : 3;
+        return;
+    }
     if (ws_force == 2 && conv16_da_eligible(BM, K, dil, stride, 0)) {  // test hook: the direct-A kernel whatever the grid
         *bn = 256; *wn = 2;
         return;
@@ -507,8 +515,11 @@ void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStre
         }
         KX_REQUIRE(a.epi != EPI_GELU_NEW, "conv1d f16x3: gelu epilogue exists only for k=1 GEMMs with >= 48 input channels");
         int bn, wn;
-        conv16_pick_tile(BM, max_cols, B, a.Cout, a.K, a.dil, a.stride, &bn, &wn, a.ws_force, a.stat_part != nullptr);
-        if (bn == 128 && wn == 1 && conv16_use_da(BM, a.K, a.dil, a.stride, a.merge_T > 0) && a.ws_force != 1)
+        conv16_pick_tile(BM, max_cols, B, a.Cout, a.K, a.dil, a.stride, &bn, &wn, a.ws_force, a.stat_part != nullptr, a.act, a.n_chunks16,
+                         a.prec1 != 0);
+        if (a.ws_force != 1 && conv16_da_s16_shape(BM, a.K, a.dil, a.stride, a.act, a.n_chunks16, a.merge_T > 0, a.prec1 != 0))
+            launch_conv1d_f16x3_da(a, B, max_cols, s, bn);  // (bn = 192 or 128: the S16 form's tiles)
+        else if (bn == 128 && wn == 1 && conv16_use_da(BM, a.K, a.dil, a.stride, a.merge_T > 0) && a.ws_force != 1)
             launch_conv1d_f16x3_da(a, B, max_cols, s, 128);  // (test hook mode 2 keeps the LDS-DMA form for comparison)
         else if (bn == 128 && wn == 1)
             launch_inst16<128, 128, 4, 1>(a, B, max_cols, s);

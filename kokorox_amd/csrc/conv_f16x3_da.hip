@@ -19,7 +19,10 @@
 // left is ONE barrier per 16-channel chunk (the input images alternate between two LDS buffers).
 // B fragments: a three-entry ring over the column tiles; a tile's three MFMAs run back to back on its accumulator and the
 // fragments of the tile two further on are read under them.
-// Three forms of the main loop:
+// Four forms of the main loop:
+//   * S16 (snake convs with 11 taps, default; KX_DA_S16=0 switches it off): v_mfma_f32_16x16x32_f16 with K = 16 channels x two
+//     taps, on a 128 x 192 tile (128 x 128 on small grids) with 64-column statistics slots; the one form whose results are not
+//     bit-identical to the others (one instruction sums 32 products) -- its two tile widths are identical to each other;
 //   * W2 (the 256-column tile's compile-time tap counts, default): the four waves as 2 x 2, each 64 rows x 128 columns, so that a
 //     B fragment read feeds six MFMAs instead of three and the MFMAs of a tile alternate between two accumulators; two ring
 //     slots of 16 registers, every vector load unconditional and every wait a compile-time constant (see "W2 form" below;
@@ -50,7 +53,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-#if !defined(KX_DA_P1) && !defined(KX_DA_W2)
+#if !defined(KX_DA_P1) && !defined(KX_DA_W2) && !defined(KX_DA_S16)
 bool conv16_da_eligible(int BM, int K, int dil, int stride, int merged) {
     return BM == 128 && stride == 1 && !merged && (K - 1) * dil + 256 <= 384;
 }
@@ -64,9 +67,12 @@ bool conv16_use_da(int BM, int K, int dil, int stride, int merged) {
 // variants, hf_cache.rs:135-144): ONE v_mfma_f32_32x32x16_f16 per product on the high halves only (weights and activations
 // rounded to f16, f32 accumulation); the low halves are neither loaded, nor computed, nor read.
 // W2: the unrolled main loop with the four waves as 2 x 2 (64 rows x 128 columns each), see "W2 form" below.
-template <int ACT, int KT, int NTT, bool P1, bool W2 = false>
-__global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(const ConvArgs a) {
+// S16: the unrolled main loop on v_mfma_f32_16x16x32_f16 (K = 32 = the 16 channels of a chunk x TWO taps), see "S16 form" below.
+template <int ACT, int KT, int NTT, bool P1, bool W2 = false, bool S16 = false>
+__global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_da_kernel(const ConvArgs a) {
     static_assert(!W2 || (KT >= 3 && (KT & 1) && NTT == 8), "W2: odd compile-time tap counts on the 256-column tile");
+    static_assert(!S16 || (KT >= 3 && (KT & 1) && !P1 && !W2), "S16: odd compile-time tap counts, three MFMAs per product, 4 x 1 waves");
+    static_assert(NTT == 8 || NTT == 4 || (NTT == 6 && S16), "tile widths: 256, 128, and 192 columns in the S16 form");
     // NTT = 8: the 128 x 256 tile of chip-filling launches; NTT = 4: 128 x 128 for small grids (batch 1), three workgroups per CU
     constexpr int BM = 128, NT = NTT, BN = 32 * NT;
     // Staged window.  Run-time tap count: BN + 128 columns = NJF 64-column blocks per wave pair, 8 channels each.
@@ -75,10 +81,13 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     // per chunk instead of 8 (NJF + 1): 20 instead of 24 on the 256-column tile (12 / 16 on the 128-column one), and a
     // sixth less input is fetched (round 2 staged 384 columns for 256 + 10 .. 50 needed).
     constexpr bool W64 = KT > 0;
-    constexpr int NJF = W64 ? BN / 128 : (BN + 128) / 128;  // whole blocks per lane
-    constexpr int NJ = NJF + (W64 ? 1 : 0);                 // + the split block
-    constexpr int HU = 8 * NJF + (W64 ? 4 : 0);             // elements per lane and chunk = half-units of the interleaved transform
+    // (the 192-column tile of the S16 form: BN + 64 = 256 columns are four WHOLE blocks, two per wave pair, no split block)
+    constexpr bool SPLIT = W64 && BN % 128 == 0;
+    constexpr int NJF = W64 ? (SPLIT ? BN / 128 : (BN + 64) / 128) : (BN + 128) / 128;  // whole blocks per lane
+    constexpr int NJ = NJF + (SPLIT ? 1 : 0);               // + the split block
+    constexpr int HU = 8 * NJF + (SPLIT ? 4 : 0);           // elements per lane and chunk = half-units of the interleaved transform
     constexpr int XWp = W64 ? BN + 64 : BN + 128;           // window pitch of one image row (columns)
+    static_assert(!W64 || SPLIT || (BN + 64) % 128 == 0, "the window is whole 64-column blocks in pairs, or ends in a split block");
     constexpr int XBUF = 4 * XWp;           // uint4 per input buffer: [hi|lo][octet][XWp]
     constexpr int tap_units = 4 * BM;       // uint4 per (chunk, tap) of the packed weights: [hi|lo][k-half][BM]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
@@ -146,6 +155,12 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[0][j][e] = 0.f;
+    constexpr int NB16 = S16 ? 2 * NT : 1;  // S16: 2 row blocks x 2 NT column blocks of 16 x 16 (the same registers)
+    f32x4v acc16[2][NB16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB16; ++j) acc16[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     // ---- input chunk staging: the scheme of conv1d_f16x3_kernel (wave w: channel octet w & 1, every other 64-column
     // block of the window; raw values and per-channel parameters of the NEXT chunk prefetched across the MFMA loop)
@@ -155,7 +170,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     int xoff[NJ];
     unsigned okmask = 0;
     // first column of the wave's block j: whole blocks alternate between the wave pairs, the split block is the window's last
-    auto blk_col = [&](int j) __attribute__((always_inline)) { return (W64 && j == NJF) ? 64 * 2 * NJF : 64 * (jb + 2 * j); };
+    auto blk_col = [&](int j) __attribute__((always_inline)) { return (SPLIT && j == NJF) ? 64 * 2 * NJF : 64 * (jb + 2 * j); };
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int p = p0 + lane + blk_col(j);
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
 #pragma unroll
             for (int j = 0; j < NJF; ++j) raw[j][c] = row[xoff[j]];
         }
-        if constexpr (W64) {
+        if constexpr (SPLIT) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int ci = ch * CK16 + g * 8 + jb * 4 + c;
@@ -260,7 +275,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         unpack_params(praw, o);
 #pragma unroll
         for (int j = 0; j < NJF; ++j) emit8(Xb, ch, lane + blk_col(j), raw[j], o, ((okmask >> j) & 1u) != 0u);
-        if constexpr (W64) emit4(Xb, ch, lane + blk_col(NJF), raw[NJF], praw, ((okmask >> NJF) & 1u) != 0u);
+        if constexpr (SPLIT) emit4(Xb, ch, lane + blk_col(NJF), raw[NJ - 1], praw, ((okmask >> NJF) & 1u) != 0u);
     };
 
     // ---- the same transform cut into HU / 2 units of one column block x one channel pair (2 of the lane's HU elements),
@@ -273,7 +288,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
 #ifdef KX_DA_NO_XFORM
     auto keep_elem = [&](const int hh) __attribute__((always_inline)) {
         const int U = hh / 2, half = hh & 1;
-        const bool split = W64 && U >= 4 * NJF;
+        const bool split = SPLIT && U >= 4 * NJF;
         const int j = split ? NJF : U % NJF, cr = split ? 2 * (U - 4 * NJF) + half : 2 * (U / NJF) + half;
         asm volatile("" ::"v"(raw[j][cr]), "v"(praw[0]), "v"(praw[1]), "v"(praw[2]), "v"(praw[3]));
     };
@@ -288,7 +303,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     // pair; both constants once inlined.
     auto xform_a = [&](const int U, const int half, int ch) __attribute__((always_inline)) {
         // units 0 .. 4 NJF - 1: whole blocks (block U % NJF, channel pair U / NJF); the last two: the split block's two pairs
-        const bool split = W64 && U >= 4 * NJF;
+        const bool split = SPLIT && U >= 4 * NJF;
         const int j = split ? NJF : U % NJF, cr = split ? 2 * (U - 4 * NJF) + half : 2 * (U / NJF) + half;  // element in raw[j]
         const int cq = split ? jb * 4 + cr : cr;                                                         // channel of the octet
         if (U == 0 && half == 0) al_rcp_x = (lane & 8) ? 1.0f / praw[3] : praw[3];
@@ -320,7 +335,7 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         }
     };
     auto xform_c = [&](const int U, const int half, uint4* Xb, int ch) __attribute__((always_inline)) {
-        const bool split = W64 && U >= 4 * NJF;
+        const bool split = SPLIT && U >= 4 * NJF;
         const int j = split ? NJF : U % NJF;
         const int c2 = split ? jb * 2 + (U - 4 * NJF) : U / NJF;  // channel pair of the octet = dword of the 16-byte slot
         const int cq = 2 * c2 + half;
@@ -389,6 +404,20 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         if constexpr (P1) asm volatile("" : "+v"(a_hi));
         else asm volatile("" : "+v"(a_hi), "+v"(a_lo));
     };
+    // S16: a ring slot holds the fragments of a PAIR of steps for the wave's two 16-row blocks: lane (row lane & 15, k-group
+    // lane >> 4) takes k-groups 0, 1 = the two channel octets of the pair's first step, 2, 3 = those of its second step, so a
+    // lane reads the same packed image at [step + (lane >> 5)][hi|lo][(lane >> 4) & 1][32 w + 16 i + (lane & 15)]: four loads.
+    const int r16 = lane & 15, tau16 = lane >> 5, h16 = (lane >> 4) & 1;
+    const uint4* wlane16 = reinterpret_cast<const uint4*>(a.w16) + (long)ct * n_steps * tap_units + (long)tau16 * tap_units + h16 * BM + wave * 32 + r16;
+    auto load_A16 = [&](int s0, u32x4 (&xh)[2], u32x4 (&xl)[2]) __attribute__((always_inline)) {
+        // (unconditional, so that the waits are compile-time constants: a pair past the end re-reads the last one, and the loop's
+        // exit keeps the registers reserved until the final wait)
+        const uint4* p = wlane16 + (long)(s0 < n_steps - 2 ? s0 : n_steps - 2) * tap_units;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xh[0]) : "v"(p) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:256" : "=v"(xh[1]) : "v"(p) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xl[0]) : "v"(p + 2 * BM) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:256" : "=v"(xl[1]) : "v"(p + 2 * BM) : "memory");
+    };
     // W2: wave (wr, wc) = (wave >> 1, wave & 1) owns rows [64 wr, 64 wr + 64) and columns [128 wc, 128 wc + 128): a ring slot
     // holds the fragments of a step for its TWO 32-row blocks (the same packed image, rows 64 wr + 32 i + r).
     const int wr2 = wave >> 1, wc2 = wave & 1;
@@ -425,9 +454,10 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     }
 #endif
     u32x4 ah0 = {0, 0, 0, 0}, al0 = {0, 0, 0, 0}, ah1 = {0, 0, 0, 0}, al1 = {0, 0, 0, 0}, ah2 = {0, 0, 0, 0}, al2 = {0, 0, 0, 0};
-    u32x4 a2h[2][2] = {}, a2l[2][2] = {};  // W2: [slot][row block]
+    u32x4 a2h[2][2] = {}, a2l[2][2] = {};  // W2 / S16: [slot][row block]
     if constexpr (W2) load_A2(0, a2h[1], a2l[1]);  // (a chunk's first step arrives in slot 1, see below)
-    if constexpr (!W2) {
+    if constexpr (S16) load_A16(0, a2h[1], a2l[1]);  // (a super-chunk's first pair likewise)
+    if constexpr (!W2 && !S16) {
     load_A(0, ah0, al0);
     load_A(1, ah1, al1);
     // (a slot that is never consumed must never be loaded: its asm result is dead to the compiler, which hands the registers
@@ -451,7 +481,161 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
         age0 = age1 = age2 = raw_ops;
     }
 
-    if constexpr (W2) {
+    if constexpr (S16) {
+        // ================= S16 form: the unrolled loop on v_mfma_f32_16x16x32_f16 ================================
+        // Why (profiles/r03_mfma_shape_probe.txt, r03_s16_form.txt): the chip is power-limited under this kernel, and the same FLOPs
+        // issued as 16x16x32 instead of 32x32x16 hold a higher clock (-9.5 % wall time in a bare loop with the same LDS operand
+        // reads; the 11-tap launches of the model: -2 .. -6 %).  The tile is 128 x 192 (and 128 x 128 on small grids): with 128
+        // accumulator registers the two 16-register ring slots do not fit beside the input prefetch (the 256-column form spills
+        // 33 - 42 VGPRs in the loop, and spills are vector-memory operations the hand-counted waits cannot tolerate); with 96 they do.
+        // The window of the 192-column tile is 256 columns = four whole 64-column blocks, two per wave pair, no split block.
+        // K = 32 is the chunk's 16 channels x TWO taps: lanes 0 .. 31 of an operand carry the pair's first step, lanes 32 .. 63
+        // the second (k-groups of 8 = channel octets), so the weight image, the LDS image and the transform are those of the
+        // 32x32x16 form.  KT is odd, so the flattened (chunk, tap) walk is paired over a SUPER-CHUNK of two chunks = KT pair-steps;
+        // the middle one straddles the two chunks (last tap of the even chunk, first tap of the odd one).  The even chunk's
+        // image lives in buffer 0, the odd one's in buffer 1:
+        //   phase A   pair-steps 0 .. HS - 1 read buffer 0; the odd chunk's transform is dealt out behind them into buffer 1
+        //   barrier 1 (buffer 1 complete), the input prefetch of the next even chunk is issued
+        //   the straddling pair-step reads both buffers; barrier 2 (buffer 0 free)
+        //   phase B   pair-steps HS + 1 .. KT - 1 read buffer 1; the next even chunk's transform goes into buffer 0
+        //   barrier 3 (buffer 0 complete), the input prefetch of the next odd chunk is issued.
+        // A ring: TWO slots of 16 registers (2 row blocks x hi/lo), pair-step p of a super-chunk in slot p & 1, refilled behind
+        // its last block for pair-step p + 2.  KT is odd, so the next super-chunk's first pair would land in slot 1: it does,
+        // and is MOVED to slot 0 (16 v_mov per super-chunk, after its wait) so that the slots stay static in the unrolled code.
+        // Per accumulator the order is that of the other forms (a_lo b_hi, a_hi b_lo, a_hi b_hi; taps and chunks ascending), but
+        // one instruction now sums 32 products: results are NOT bit-identical to the 32x32x16 forms (both tile widths of this
+        // form are identical to each other -- batch invariance; against the oracle the error is the same 1e-6 class).
+        static_assert(W64, "S16: the 64-column window of the unrolled forms");
+        constexpr int NB = 2 * NT;          // 16-column blocks per pair-step
+        constexpr int HS = (KT - 1) / 2;    // pair-steps wholly inside one chunk
+        constexpr int TB = KT * NB;         // blocks per super-chunk (6 MFMAs each)
+        constexpr int NA = HS * NB;         // blocks before the straddling pair-step (and behind it)
+        constexpr int SB0 = (HS + 1) * NB;  // first block behind it
+        const int n_super = n_chunks >> 1;
+        const int d_norm = tau16 ? dil : 0, d_str = tau16 ? XBUF - (KT - 1) * dil : 0;
+        half8 fh[2], fl[2];
+        // B fragments of block nb of pair-step p: lane (column lane & 15, k-group lane >> 4) reads 16 B of the first step's tap
+        // (lanes 0 .. 31) or the second step's (lanes 32 .. 63: + dil, or across to buffer 1 in the straddling pair)
+        // (xl_it, dil_it: the loop-invariant lane base and dilation, made opaque once per super-chunk -- otherwise all KT x NB
+        // fragment addresses are hoisted out of the loop and live in registers: 330 spilled VGPRs)
+        int xl_it = h16 * XWp + r16;  // (an index, not a pointer: a pointer through asm loses its LDS address space -> flat loads)
+        int dil_it = dil;
+        auto load_blk = [&](const int p, const int nb, half8& fhx, half8& flx) __attribute__((always_inline)) {
+            const int f0 = 2 * p, b0 = f0 >= KT ? 1 : 0, tp = f0 - b0 * KT;
+            const uint4* xt = Xs + (xl_it + b0 * XBUF + tp * dil_it + (f0 == KT - 1 ? d_str : d_norm) + nb * 16);
+            fhx = *reinterpret_cast<const half8*>(xt);
+            flx = *reinterpret_cast<const half8*>(xt + 2 * XWp);
+        };
+        // Every vector-memory operation of the loop is issued unconditionally, so the age of a slot at its wait is a constant:
+        // the refill of the OTHER slot (4 loads) and, where barrier 1 or 3 lies in between, one input prefetch batch.
+        auto age_of = [](const int p) constexpr {
+            if (p == 0) return raw_ops;                               // refilled behind pair-step KT - 2; barrier 3's prefetch since
+            return 4 + ((HS == p - 1 || HS == p) ? raw_ops : 0);      // (p = 1: refilled at the super-chunk's start)
+        };
+        // first transform part: blocks into a phase (the input prefetch was issued at the phase's start in A, a pair-step
+        // earlier in B)
+#ifndef KX_S16_I0A_LONG
+#define KX_S16_I0A_LONG 32
+#endif
+#ifndef KX_S16_I0A_MID
+#define KX_S16_I0A_MID 16
+#endif
+#ifndef KX_S16_I0B
+#define KX_S16_I0B 8
+#endif
+        constexpr int I0A = (KT >= 9 ? KX_S16_I0A_LONG : KX_S16_I0A_MID) * NT / 8, I0B = KX_S16_I0B * NT / 8;
+        static_assert(I0A < NA && I0B < NA, "S16: the transform needs blocks to ride on");
+#ifndef KX_S16_G
+#define KX_S16_G 2
+#endif
+        constexpr int G = KX_S16_G;  // blocks per scheduling region
+        load_blk(0, 0, fh[0], fl[0]);
+        for (int sc = 0; sc < n_super; ++sc) {
+            const int ch0 = 2 * sc, P0 = sc * KT;  // (pair-step P of the launch = steps 2 P, 2 P + 1)
+            asm volatile("" : "+v"(xl_it), "+s"(dil_it));
+            static_for<0, TB>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int p = i / NB, nb = i % NB, sl = p & 1, e = i & 1, ip = i + 1;
+                if constexpr (nb == 0 && p == 0) {
+                    wait_A2(age_of(0), a2h[1], a2l[1]);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        a2h[0][q] = a2h[1][q];
+                        a2l[0][q] = a2l[1][q];
+                    }
+                    asm volatile("" : "+v"(a2h[0][0]), "+v"(a2h[0][1]), "+v"(a2l[0][0]), "+v"(a2l[0][1]));  // (copies made HERE)
+                    load_A16(2 * (P0 + 1), a2h[1], a2l[1]);
+                } else if constexpr (nb == 0) {
+                    if constexpr (p == HS) {
+                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier 1
+                        load_raw(ch0 + 2 < n_chunks ? ch0 + 2 : n_chunks - 1);
+                        load_blk(p, 0, fh[e], fl[e]);
+                    }
+                    if constexpr (p == HS + 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier 2
+                    wait_A2(age_of(p), a2h[sl], a2l[sl]);
+                }
+                const half8 a0h = __builtin_bit_cast(half8, a2h[sl][0]), a1h = __builtin_bit_cast(half8, a2h[sl][1]);
+                const half8 a0l = __builtin_bit_cast(half8, a2l[sl][0]), a1l = __builtin_bit_cast(half8, a2l[sl][1]);
+                // the next block's fragments (not across barriers 1 and 3: the image they read is still being written)
+                if constexpr (ip < TB && !(ip == HS * NB)) load_blk(ip / NB, ip % NB, fh[e ^ 1], fl[e ^ 1]);
+                if constexpr (i % G == 0) __builtin_amdgcn_sched_barrier(0);
+                acc16[0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l, fh[e], acc16[0][nb], 0, 0, 0);
+                acc16[1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l, fh[e], acc16[1][nb], 0, 0, 0);
+                acc16[0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, fl[e], acc16[0][nb], 0, 0, 0);
+                acc16[1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, fl[e], acc16[1][nb], 0, 0, 0);
+                acc16[0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, fh[e], acc16[0][nb], 0, 0, 0);
+                acc16[1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, fh[e], acc16[1][nb], 0, 0, 0);
+                // half-units of the transform riding on this block: phase A -> the odd chunk into buffer 1, phase B -> the next
+                // even chunk into buffer 0 (in the last super-chunk: stale registers into an image nobody reads)
+                constexpr bool inA = i < NA, inB = i >= SB0;
+                constexpr int rel = inA ? i : i - SB0, I0 = inA ? I0A : I0B;
+                constexpr int h0 = (inA || inB) && rel > I0 ? ((rel - I0) * HU) / (NA - I0) : 0;
+                constexpr int h1 = (inA || inB) && rel + 1 > I0 ? ((rel + 1 - I0) * HU) / (NA - I0) : 0;
+                static_assert(h1 - h0 <= 2, "at most two half-units per block");
+                uint4* Xdst = Xs + (inA ? 1 : 0) * XBUF;
+                if constexpr (h1 > h0) {
+                    xform_a(h0 / 2, h0 & 1, 0);
+                    xform_b();
+                    xform_c(h0 / 2, h0 & 1, Xdst, 0);
+                }
+                if constexpr (h1 > h0 + 1) {
+                    xform_a((h0 + 1) / 2, (h0 + 1) & 1, 0);
+                    xform_b();
+                    xform_c((h0 + 1) / 2, (h0 + 1) & 1, Xdst, 0);
+                }
+                if constexpr (i % G == G - 1) {  // the pipeline of the region: the half-units spread over its 6 G MFMAs
+                    constexpr int ig = i - (G - 1);
+                    constexpr bool gA = ig < NA, gB = ig >= SB0;
+                    constexpr int grel = gA ? ig : ig - SB0, gI0 = gA ? I0A : I0B;
+                    constexpr int hg0 = (gA || gB) && grel > gI0 ? ((grel - gI0) * HU) / (NA - gI0) : 0;
+                    constexpr int nh = h1 > hg0 ? h1 - hg0 : 0;
+                    constexpr int per = nh > 0 ? (nh * 27 + 6 * G - 1) / (6 * G) : 0;
+#pragma unroll
+                    for (int tg = 0; tg < G; ++tg) {
+                        if (tg > 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                        for (int k6 = 0; k6 < 6; ++k6) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            if (per > 0) __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (nb == NB - 1) {  // refill the slot with the pair-step two further on
+                    if constexpr (p + 2 <= KT - 1) load_A16(2 * (P0 + p + 2), a2h[sl], a2l[sl]);
+                    else if constexpr (p == KT - 2) load_A16(2 * (P0 + KT), a2h[1], a2l[1]);  // (slot 1: the next super-chunk's first pair)
+                }
+            });
+            // (barrier 3 and what follows run after the last super-chunk too: one barrier and one prefetch batch nobody reads, for
+            // a loop without a run-time condition in it)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier 3
+            load_raw(ch0 + 3 < n_chunks ? ch0 + 3 : n_chunks - 1);
+            load_blk(0, 0, fh[0], fl[0]);
+        }
+        (void)n_super;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::"v"(a2h[1][0]), "v"(a2h[1][1]), "v"(a2l[1][0]), "v"(a2l[1][1]));  // (reserved until here)
+    } else if constexpr (W2) {
         // ================= W2 form: the unrolled loop with the waves as 2 x 2 ===================================
         // Why (profiles/r03_mfma_shape_probe.txt): the chip is power-limited under this kernel and the LDS operand reads are 7 % of
         // a bare MFMA loop's time; with 64 x 128 wave tiles a B fragment feeds six MFMAs instead of three (-4.8 % there), and the
@@ -826,7 +1010,14 @@ __global__ __launch_bounds__(256, NTT == 8 ? 2 : 3) void conv1d_f16x3_da_kernel(
     float2* stat_scr = reinterpret_cast<float2*>(smem16) + wave * (32 * 33);
     float* wide_scr = reinterpret_cast<float*>(stat_scr);  // (the wide store's 4 KiB transpose scratch, same per-wave region)
     // 128-column groups of four column tiles = the statistics groups of the other tile shapes
-    if constexpr (W2) {
+    if constexpr (S16) {
+        // 64-column groups = the statistics slots of this form (both of its tile widths: batch invariance)
+        static_for<0, NT / 2>([&](auto gc) __attribute__((always_inline)) {
+            constexpr int g2 = decltype(gc)::value;
+            conv_store_group16<EPI_ROWS, NB16, 2>(a, acc16, 4 * g2, a.w_unscale, b, ct * BM + wave * 32, t0 + 64 * g2, lane, ncols, Lout,
+                                                  tile_x * (NT / 2) + g2, stat_scr, wide_scr);
+        });
+    } else if constexpr (W2) {
         conv_store_group<EPI_ROWS>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][0]), a.w_unscale, b, ct * BM + wr2 * 64, t0 + 128 * wc2, r,
                                    h, ncols, Lout, tile_x * 2 + wc2, stat_scr, wide_scr);
         conv_store_group<EPI_ROWS>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][4]), a.w_unscale, b, ct * BM + wr2 * 64 + 32, t0 + 128 * wc2,
@@ -868,9 +1059,15 @@ constexpr bool DA_W2 = true;
 constexpr bool DA_W2 = false;
 #endif
 
+#ifdef KX_DA_S16
+constexpr bool DA_S16 = true;
+#else
+constexpr bool DA_S16 = false;
+#endif
+
 template <int ACT, int KT, int NTT>
 static void launch_da_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
-    auto kern = conv1d_f16x3_da_kernel<ACT, KT, NTT, DA_P1, DA_W2>;
+    auto kern = conv1d_f16x3_da_kernel<ACT, KT, NTT, DA_P1, DA_W2, DA_S16>;
     constexpr int BN = 32 * NTT;
     // two input buffers (48 / 32 KiB), and never less than the statistics scratch of the epilogue (4 waves x 8.25 KiB)
     constexpr size_t lds_x = 16 * (size_t)2 * 4 * (BN + 128), lds_scr = 4 * 32 * 33 * sizeof(float2);
@@ -881,7 +1078,25 @@ static void launch_da_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s
     KX_HIP(hipGetLastError());
 }
 
-#ifdef KX_DA_W2
+#ifdef KX_DA_S16
+// The S16 forms (conv_f16x3_da_s16.hip defines KX_DA_S16 and includes this file).
+// Shapes the S16 form takes (and conv16_pick_tile gives 64-column statistics slots): snake resblock convs with 11 taps and an even
+// number of 16-channel chunks.  KX_DA_S16=0 switches the form off.  (The 7-tap convs were measured on it too: the big launches
+// -3 %, the dilated ones +3 %, no net gain -- profiles/r03_s16_form.txt -- and are not instantiated.)
+bool conv16_da_s16_shape(int BM, int K, int dil, int stride, int act, int n_chunks16, bool merged, bool prec1) {
+    static const int on = getenv("KX_DA_S16") ? atoi(getenv("KX_DA_S16")) : 1;
+    static const int da = getenv("KX_DA") ? atoi(getenv("KX_DA")) : 1;
+    static const int st = getenv("KX_DA_STATIC") ? atoi(getenv("KX_DA_STATIC")) : 1;
+    return on && da && st && BM == 128 && stride == 1 && !merged && !prec1 && act == ACT_SNAKE && K == 11 && (K - 1) * dil <= 64 &&
+           n_chunks16 >= 2 && (n_chunks16 & 1) == 0;
+}
+void launch_conv1d_f16x3_da_s16(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn) {
+    KX_REQUIRE(conv16_da_s16_shape(128, a.K, a.dil, a.stride, a.act, a.n_chunks16, a.merge_T > 0, a.prec1 != 0), "conv1d f16x3 da s16: launch not eligible");
+    KX_REQUIRE(bn == 192 || bn == 128, "conv1d f16x3 da s16: tile of 192 or 128 columns");
+    if (bn == 192) launch_da_inst<ACT_SNAKE, 11, 6>(a, B, max_cols, s);
+    else launch_da_inst<ACT_SNAKE, 11, 4>(a, B, max_cols, s);
+}
+#elif defined(KX_DA_W2)
 // The W2 forms (conv_f16x3_da_w2.hip defines KX_DA_W2 and includes this file): the unrolled forms of the 256-column tile;
 // launch_da_ntt<8> of the main translation unit forwards here.  Results are bit-identical to the forms they replace.
 // (The reduced-precision mode keeps the 4 x 1 layout: its W2 instantiations measured 78.2 against 78.4 ms per step -- that mode is
@@ -901,6 +1116,7 @@ void launch_conv1d_f16x3_da_w2(const ConvArgs& a, int B, int max_cols, hipStream
 #else
 bool conv16_da_w2_has(int act, int K);                                                          // conv_f16x3_da_w2.hip
 void launch_conv1d_f16x3_da_w2(const ConvArgs& a, int B, int max_cols, hipStream_t s);  // conv_f16x3_da_w2.hip
+void launch_conv1d_f16x3_da_s16(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn);  // conv_f16x3_da_s16.hip
 
 template <int NTT>
 static void launch_da_ntt(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
@@ -935,7 +1151,7 @@ static void launch_da_ntt(const ConvArgs& a, int B, int max_cols, hipStream_t s)
 
 #endif  // KX_DA_W2
 
-#if defined(KX_DA_W2)
+#if defined(KX_DA_W2) || defined(KX_DA_S16)
 #elif defined(KX_DA_P1)
 // bn: 256 or 128, as launch_conv1d_f16x3_da (which forwards here when a.prec1 is set)
 void launch_conv1d_f16x3_da_p1(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn) {
@@ -952,8 +1168,15 @@ void launch_conv1d_f16x3_da(const ConvArgs& a, int B, int max_cols, hipStream_t 
     KX_REQUIRE(conv16_da_eligible(128, a.K, a.dil, a.stride, a.merge_T > 0), "conv1d f16x3 da: launch not eligible");
     KX_REQUIRE(a.n_chunks16 == (a.Cin + CK16 - 1) / CK16 && a.w16 != nullptr, "conv1d f16x3 da: weights not packed");
     KX_REQUIRE(a.epi != EPI_GELU_NEW, "conv1d f16x3 da: no gelu epilogue");
-    KX_REQUIRE(bn == 256 || bn == 128, "conv1d f16x3 da: tile of 256 or 128 columns");
+    KX_REQUIRE(bn == 256 || bn == 128 || bn == 192, "conv1d f16x3 da: tile of 256, 192 or 128 columns");
     if (max_cols <= 0) return;
+    // 7 / 11-tap snake convs: the 16x16x32 form on its 192- or 128-column tile (conv16_pick_tile chose bn and the 64-column
+    // statistics slots for it by the same predicate)
+    if (conv16_da_s16_shape(128, a.K, a.dil, a.stride, a.act, a.n_chunks16, a.merge_T > 0, a.prec1 != 0)) {
+        launch_conv1d_f16x3_da_s16(a, B, max_cols, s, bn == 128 ? 128 : 192);
+        return;
+    }
+    KX_REQUIRE(bn != 192, "conv1d f16x3 da: the 192-column tile exists in the S16 form only");
     if (a.prec1) {
         launch_conv1d_f16x3_da_p1(a, B, max_cols, s, bn);
         return;

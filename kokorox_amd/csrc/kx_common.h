@@ -119,8 +119,9 @@ size_t packed_conv_floats(int rows, int Cin, int K, int BM);
 // f16x3 split path
 enum ConvMode { CONV_F32 = 0, CONV_F16X3 = 1, CONV_F16X3_LDS = 2, CONV_F16X3_DA = 3, CONV_F16 = 4 };  // (2, 3: test hook only: f16x3 kept on the LDS-DMA kernel forms of conv_f16x3.hip / forced through conv_f16x3_da.hip)
 void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStream_t s);
+// (act / n_chunks16 / prec1: given, the shapes of the direct-A S16 form get its tiles: 192 or 128 columns, 64-column statistics slots)
 void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int stride, int* bn, int* wn,
-                      int ws_force = 0, bool stats = false);  // (conv_f16x3.hip)
+                      int ws_force = 0, bool stats = false, int act = -1, int n_chunks16 = 0, bool prec1 = false);  // (conv_f16x3.hip)
 // conv_f16x3_da.hip: the 128 x 256 tile with the weight fragments loaded from global memory straight into registers
 bool conv16_use_da(int BM, int K, int dil, int stride, int merged);       // eligible AND switched on (default; KX_DA=0 turns it off)
 bool conv16_da_eligible(int BM, int K, int dil, int stride, int merged);  // shape fits the kernel
@@ -130,6 +131,8 @@ bool conv16_use_dag(const ConvArgs& a, int BM);       // eligible AND switched o
 bool conv16_dag_eligible(const ConvArgs& a, int BM);
 void launch_conv1d_f16x3_dag(const ConvArgs& a, int B, int max_cols, hipStream_t s);
 int conv16_cu_count();  // CUs of the current device (conv_f16x3.hip)
+// shapes that take the 16x16x32 form of the direct-A conv (conv_f16x3_da_s16.hip): 192 / 128-column tiles, 64-column statistics slots
+bool conv16_da_s16_shape(int BM, int K, int dil, int stride, int act, int n_chunks16, bool merged, bool prec1);
 size_t packed_conv16_halves(int rows, int Cin, int K, int BM);
 float device_absmax(const float* p, long n, hipStream_t s);
 int pick_weight_shift(float absmax);

@@ -110,12 +110,12 @@ def _prefetch_batches(lines):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
-@pytest.mark.parametrize("src", ["conv_f16x3_da.hip", "conv_f16x3_da_p1.hip", "conv_f16x3_da_w2.hip"])  # f16x3, reduced precision, 2 x 2 waves
+@pytest.mark.parametrize("src", ["conv_f16x3_da.hip", "conv_f16x3_da_p1.hip", "conv_f16x3_da_w2.hip", "conv_f16x3_da_s16.hip"])  # f16x3, reduced precision, 2 x 2 waves, 16x16x32
 def test_direct_a_conv_assembly(tmp_path, src):
     ks = _kernels(_asm(src, tmp_path, "-DKX_DA_AUDIT"))
     assert ks, "no kernel found"
     # every instantiation launch_da_ntt can select, both tile widths; the four unrolled 256-column forms of the 2 x 2 layout
-    assert len(ks) == (4 if src == "conv_f16x3_da_w2.hip" else 14), sorted(ks)
+    assert len(ks) == {"conv_f16x3_da_w2.hip": 4, "conv_f16x3_da_s16.hip": 2}.get(src, 14), sorted(ks)
     for name, lines in ks.items():
         assert not any("scratch_" in ln for ln in lines), f"{name} spills"
         bad = _audit_no_touch_before_wait(lines)
@@ -125,6 +125,8 @@ def test_direct_a_conv_assembly(tmp_path, src):
         # elements per lane and chunk: BN + 128 staged columns in the run-time form, BN + 64 (last block split over the four
         # waves by channel) in the unrolled forms
         hu = 8 * (ntt // 4) + 4 if kt > 0 else (32 * ntt + 128) // 128 * 8
+        if ntt == 6:
+            hu = 16  # (the 192-column tile of the S16 form: a window of four whole 64-column blocks, no split block)
         want = hu + 3 + (1 if act == 2 else 0)  # raw_ops with the three InstanceNorm parameter loads present
         sizes = _prefetch_batches(lines)
         assert sizes and all(sz == want for sz in sizes), f"{name}: input prefetch is {sizes} loads, raw_ops assumes {want}"

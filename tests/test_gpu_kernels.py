@@ -307,6 +307,14 @@ def test_direct_a_kernel_is_bit_identical_under_load(B, Cin, Cout, L, k, d):
         y1 = hk.conv1d(x, w, b, pad=p, dil=d, mode=1, **kw)   # what the model launches (direct-A on this grid)
         y3 = hk.conv1d(x, w, b, pad=p, dil=d, mode=3, **kw)   # direct-A forced
         assert np.isfinite(y3).all()
+        if k == 11 and kw:
+            # snake convs with 11 taps run on v_mfma_f32_16x16x32_f16 (S16 form): one instruction sums 32 products, so the
+            # comparison with the 32x32x16 forms is a tolerance (measured 3 - 5e-6 on O(1) outputs); a fragment used before it
+            # has landed would show as a far larger error or as a difference between two runs
+            assert 0 < np.abs(y2 - y3).max() < 2e-5
+            np.testing.assert_array_equal(y1, y3)
+            np.testing.assert_array_equal(y3, hk.conv1d(x, w, b, pad=p, dil=d, mode=3, **kw))
+            continue
         np.testing.assert_array_equal(y2, y3)
         np.testing.assert_array_equal(y2, y1)
     res = rng.standard_normal(y1.shape, dtype=np.float32)
@@ -340,9 +348,33 @@ def test_direct_a_4x1_layout_of_the_256_column_tile_is_still_bit_identical():
         "print('same bits')\n")
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, KX_DA_W2="0"), capture_output=True, text=True,
-                       timeout=600)
+    # (KX_DA_S16=0: the 11-tap case would otherwise take the 16x16x32 form, which is not bit-identical by construction)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, KX_DA_W2="0", KX_DA_S16="0"), capture_output=True,
+                       text=True, timeout=600)
     assert r.returncode == 0 and "same bits" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_s16_form_gives_the_same_bits_on_both_of_its_tile_widths():
+    """The 16x16x32 form of the 11-tap snake convs runs on a 128-column tile on small grids and on a 192-column tile on
+    chip-filling ones; an utterance must come out bit-identical either way (batch invariance): the same utterance alone (98
+    tiles of 256 -> small grid) and as member 2 of a batch of eight (chip-filling), against each other and, within the
+    tolerance of the K = 32 summation, against the LDS form."""
+    from kokorox_amd import hip_koko as hk
+    rng = np.random.default_rng(16)
+    B, C, L, k, d = 8, 128, 25000, 11, 3
+    x = rng.standard_normal((B, C, L), dtype=np.float32)
+    w = (rng.standard_normal((C, C, k), dtype=np.float32) / np.sqrt(C * k)).astype(np.float32)
+    b = rng.standard_normal(C, dtype=np.float32)
+    alpha = (0.5 + rng.random(C)).astype(np.float32)
+    norm = rng.standard_normal((3, B, C), dtype=np.float32)  # (the hook's layout: planes of mean, scale, shift, each [B][C])
+    norm[1] = 1.0 + 0.1 * norm[1]
+    kw = dict(pad=d * (k - 1) // 2, dil=d, act=2, alpha=alpha)
+    y_batch = hk.conv1d(x, w, b, norm=norm, mode=1, **kw)
+    y_alone = hk.conv1d(x[2:3], w, b, norm=np.ascontiguousarray(norm[:, 2:3]), mode=1, **kw)
+    np.testing.assert_array_equal(y_batch[2:3], y_alone)
+    y_lds = hk.conv1d(x[2:3], w, b, norm=np.ascontiguousarray(norm[:, 2:3]), mode=2, **kw)
+    assert 0 < np.abs(y_lds - y_alone).max() < 2e-5
 
 
 @pytest.mark.gpu
