@@ -1044,44 +1044,63 @@ __global__ void istft_spec_kernel(const float* cp, long bs, int ld, float* spec,
 }
 __global__ void istft_ola_kernel(const float* spec, long bs, int ld, float* audio, long audio_ld, const int* frames,
                                  int variant) {
-    // the inverse-DFT rows are indexed by the sample's position in its frame, which differs from lane to lane: from constant
+    // The inverse-DFT rows are indexed by the sample's position in its frame, which differs from lane to lane: from constant
     // memory that is one scalar load per distinct index (808 us per batch-64 launch); from LDS it is an ordinary banked read.
-    // The spectrum columns a block's 256 samples touch (57 frames x 22 rows) are staged in LDS too: every sample reads 88 of
-    // them, five neighbouring samples the same ones (407 -> ~100 us).
-    constexpr int FW = 60;  // frames staged per block: samples j0 .. j0 + 255 touch frames (j0 - 5) / 5 .. (j0 + 265) / 5
+    // The spectrum columns a block's samples touch are staged in LDS too: every sample reads 88 of them, five neighbouring
+    // samples the same ones (407 -> 248 us).  And a thread takes one HOP of five consecutive samples (n = 5 q + 10 .. + 4: the
+    // same four frames q - 1 .. q + 2 for all five), so the 88 spectrum values are read once per five samples and every
+    // coefficient read is the same address in all lanes (a broadcast): 248 -> 196 us.  Per sample the frames are still added
+    // in descending order and the bins in ascending order, as before.
+    constexpr int HPB = 256;      // hops (threads) per block = 1280 samples
+    constexpr int FW = HPB + 4;   // frames staged: hop q touches frames q - 1 .. q + 2
     __shared__ float s_re[20][11], s_im[20][11], s_wsq[20];
     __shared__ float s_sp[22][FW];
-    const int b = blockIdx.y, j0 = blockIdx.x * blockDim.x;
-    const int nf = 120 * frames[b] + 1;
-    if (j0 >= 600 * frames[b]) return;  // (block-uniform)
+    const int b = blockIdx.y, q0 = blockIdx.x * HPB;
+    const int nf = 120 * frames[b] + 1, ns = 600 * frames[b];
+    if (5 * q0 >= ns) return;  // (block-uniform)
     for (int i = threadIdx.x; i < 220; i += blockDim.x) {
         s_re[i / 11][i % 11] = c_inv_re[variant][i / 11][i % 11];
         s_im[i / 11][i % 11] = c_inv_im[variant][i / 11][i % 11];
     }
     if (threadIdx.x < 20) s_wsq[threadIdx.x] = c_win_sq[threadIdx.x];
-    const int f0 = j0 >= 9 ? (j0 - 5) / 5 : 0;  // first frame any sample of the block reads (flo of its first sample)
+    const int f0 = q0 - 1;  // (may be -1: staged as zero, never read)
     const float* sp = spec + b * bs;
     for (int i = threadIdx.x; i < 22 * FW; i += blockDim.x) {
         const int k = i / FW, f = f0 + i % FW;
-        s_sp[k][i % FW] = f < nf ? sp[(long)k * ld + f] : 0.f;
+        s_sp[k][i % FW] = (f >= 0 && f < nf) ? sp[(long)k * ld + f] : 0.f;
     }
     __syncthreads();
-    const int j = j0 + threadIdx.x;
-    if (j >= 600 * frames[b]) return;
-    const int n = j + 10;
-    int fhi = n / 5;
-    if (fhi > nf - 1) fhi = nf - 1;
-    const int flo = n >= 19 ? (n - 15) / 5 : 0;
-    float y = 0.f, env = 0.f;
-    for (int f = fhi; f >= flo; --f) {
-        const int m = n - 5 * f;
-        float acc = 0.f;
+    const int q = q0 + threadIdx.x;  // samples j = 5 q .. 5 q + 4, n = j + 10 = 5 (q + 2) + s
+    if (5 * q >= ns) return;
+    float y[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, env[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    // sample s of the hop: fhi = (n / 5) = q + 2, flo = (n - 15) / 5 = q - 1 (n >= 19) -- clamped as before
 #pragma unroll
-        for (int k = 0; k < 11; ++k) acc += s_re[m][k] * s_sp[k][f - f0] + s_im[m][k] * s_sp[11 + k][f - f0];
-        y += acc;
-        env += s_wsq[m];
+    for (int df = 3; df >= 0; --df) {  // frame f = q - 1 + df, descending
+        const int f = q - 1 + df;
+        if (f > nf - 1 || f < 0) continue;
+        float re[11], im[11];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            re[k] = s_sp[k][f - f0];
+            im[k] = s_sp[11 + k][f - f0];
+        }
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) {
+            const int n = 5 * q + 10 + s5;
+            const int m = n - 5 * f;  // = 5 (3 - df) + s5: a compile-time constant once unrolled
+            // (the first samples of the signal, n < 19, reach back only to frame 0: f >= 0 above enforces it)
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) acc += s_re[m][k] * re[k] + s_im[m][k] * im[k];
+            y[s5] += acc;
+            env[s5] += s_wsq[m];
+        }
     }
-    audio[b * audio_ld + j] = variant == 0 ? y : y / env;
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) {
+        const int j = 5 * q + s5;
+        if (j < ns) audio[b * audio_ld + j] = variant == 0 ? y[s5] : y[s5] / env[s5];
+    }
 }
 void launch_istft_head(const float* cp, long bs, int ld, float* spec_ws, float* audio, long audio_ld,
                        const int* frames, int B, int Fmax, int variant, hipStream_t s) {
@@ -1089,8 +1108,8 @@ void launch_istft_head(const float* cp, long bs, int ld, float* spec_ws, float* 
     hipLaunchKernelGGL(istft_spec_kernel, dim3((nfmax + 255) / 256, 11, B), dim3(256), 0, s, cp, bs, ld, spec_ws,
                        frames);
     KX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(istft_ola_kernel, dim3((600 * Fmax + 255) / 256, B), dim3(256), 0, s, spec_ws, bs, ld, audio,
-                       audio_ld, frames, variant);
+    hipLaunchKernelGGL(istft_ola_kernel, dim3((120 * Fmax + 255) / 256, B), dim3(256), 0, s, spec_ws, bs, ld, audio,
+                       audio_ld, frames, variant);  // (one thread per hop of five samples)
     KX_HIP(hipGetLastError());
 }
 
