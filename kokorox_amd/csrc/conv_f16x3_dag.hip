@@ -391,7 +391,8 @@ void launch_conv1d_f16x3_dag(const ConvArgs& a, int B, int max_cols, hipStream_t
     if (max_cols <= 0) return;
     // at most half as many 128 x 128 tiles as CUs: the narrow form (KX_DAGN=0: never, 2: always; results are bit-identical either
     // way).  Measured by batch, off / on: 1: 11.85 / 10.55 ms, 4: 16.74 / 15.73, 16: 36.6 / 36.5; at 32 and 64 no launch qualifies
-    // (forced everywhere it costs 3 - 5 %: four times the weight traffic and the split repeated by four waves).
+    // (forced everywhere it costs 3 - 5 %: four times the weight traffic and the split repeated by four waves; on the 390-tile grids of the
+    // 768-row GEMMs at batch 64 alone it is twice as slow as the 128 x 128 form: 3.09 against 1.59 ms for 12 launches).
     static const int narrow = getenv("KX_DAGN") ? atoi(getenv("KX_DAGN")) : 1;
     const long wgs = (long)((max_cols + 127) / 128) * ((a.Cout + 127) / 128) * (a.merge_T > 0 ? 1 : B);
     // (the narrow form: whole chunks only, and 32-bit byte offsets into the input)
