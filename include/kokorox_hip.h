@@ -44,11 +44,23 @@ typedef struct kx_model kx_model;
  * err/err_len: optional buffer for a message when the return value is not KX_OK. */
 int kx_init(int device_id, char* err, size_t err_len);
 
-/* Replaces `OrtKoko::new(model_path)` → `OrtBase::load_model`
- * (kokorox/src/onn/ort_koko.rs:31-35, ort_base.rs:14-39): reads a KXHIPW01 weight file
- * (kokorox_amd/weights.py), uploads it, repacks the contraction weights for the MFMA
- * kernels.  Returns NULL on failure with the reason in err. */
+/* Replaces `OrtKoko::new(model_path)` → `OrtBase::load_model` → `commit_from_file`
+ * (kokorox/src/onn/ort_koko.rs:31-35, ort_base.rs:14-39; call site kokorox/src/tts/koko.rs:570-573).
+ * `weights_path` is what the reference passes there: the Hugging Face `onnx/model.onnx` (path built at
+ * kokorox/src/utils/hf_cache.rs:128-158; its fp16 / int8 / 4-bit siblings of hf_cache.rs:135-144 load as well, their
+ * weights de-quantised to f32).  The library reads the ONNX initialisers itself (csrc/onnx_import.cpp: no protobuf
+ * package, no ONNX Runtime), places them by the rules of kokorox_amd/importer.py, uploads them and repacks the
+ * contraction weights for the MFMA kernels.  A file that starts with the magic "KXHIPW01" is taken as the library's own
+ * pre-converted container (kokorox_amd/weights.py) instead; `<path>.kxw` beside an .onnx is used when it is at least as
+ * new as the .onnx, and written when the environment has KOKOROX_KXW_CACHE=1.
+ * Returns NULL on failure with the reason in err (KX_ERR_IO class: missing / truncated / external-data files, tensors
+ * of the model that could not be found — the message lists initialisers that were not placed). */
 kx_model* kx_create(const char* weights_path, int device_id, char* err, size_t err_len);
+
+/* Host only (no GPU is touched): `model.onnx` → the KXHIPW01 container kx_create would build from it in memory, written
+ * to out_path — for a deployment that wants to convert once (the bytes equal `python -m kokorox_amd.importer`'s).
+ * No reference counterpart: ONNX Runtime parses the file on every start (ort_base.rs:27-33). */
+int kx_import_onnx(const char* onnx_path, const char* out_path, char* err, size_t err_len);
 
 /* Same, from a weight blob that is ALREADY resident in this GPU's memory, e.g. after the
  * one-time RCCL broadcast over xGMI.  The blob is borrowed for the
@@ -58,7 +70,7 @@ kx_model* kx_create_from_device_blob(const void* d_blob, size_t n_bytes, int dev
                                      char* err, size_t err_len);
 
 /* One model per GPU for the server (the reference's server is ONE process, kokorox-openai/src/lib.rs:
- * 370-439): reads the weight file ONCE, uploads it to device_ids[0] over PCIe and fans it out to the other
+ * 370-439): reads the weight file ONCE (`.onnx` or container, as kx_create), uploads it to device_ids[0] over PCIe and fans it out to the other
  * devices with concurrent device-to-device copies (hipMemcpyPeerAsync, one xGMI link per destination), then builds
  * every model from its resident blob.  out_models[n] receives the handles, ready for kx_dispatcher_create; ids may
  * repeat (several models on one GPU).  On failure nothing is leaked and every entry of out_models is NULL.
@@ -263,6 +275,16 @@ int kx_test_conv1d_epilogue(int device_id, const float* x, int B, int Cin, int L
                             const float* bias, int Cout, int k, int pad, int dil, const float* resid,
                             int accumulate, float out_mul, float out_div, float* y, float* stats_out,
                             int mode, char* err, size_t err_len);
+
+/* Both at once, as the generator's resblock convs run: fused AdaIN affine + activation on the input AND the epilogue forms
+ * (residual / running sum / scale / fused statistics), on a RAGGED batch when lens [B] is given (utterance b is lens[b]
+ * columns long: columns past its output length stay as they were, its statistics cover its own columns only) and, with
+ * pad_ld != 0, on rows padded to a multiple of 32 floats as the model lays them out (input and residual padding is NaN,
+ * the output padding holds a sentinel that must survive).  Stride 1, not transposed. */
+int kx_test_conv1d_full(int device_id, const float* x, int B, int Cin, int L, const int32_t* lens, int pad_ld,
+                        const float* w, const float* bias, int Cout, int k, int pad, int dil, int act, float slope,
+                        const float* alpha, const float* norm, const float* resid, int accumulate, float out_mul,
+                        float out_div, float* y, float* stats_out, int mode, char* err, size_t err_len);
 
 /* Stand-alone bidirectional LSTM (hidden 256): x [B,L,n_in] -> y [B,L,512]. */
 int kx_test_lstm(int device_id, const float* x, int B, int L, int n_in, const float* w_ih,

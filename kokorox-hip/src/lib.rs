@@ -11,8 +11,11 @@
 //! ```
 //!
 //! Change in the reference: `use kokorox_hip::HipKoko as OrtKoko;` at kokorox/src/tts/koko.rs:40,570-573 and
-//! `kokorox_hip::init(0)` in place of `init_ort` (koko/src/main.rs:1429).  The weight file is the KXHIPW01 blob
-//! written by `python -m kokorox_amd.importer` (from `model.onnx`, a `.pth` or safetensors), not the `.onnx`.
+//! `kokorox_hip::init(0)` in place of `init_ort` (koko/src/main.rs:1429).  `model_path` stays what the reference
+//! passes: the Hugging Face `onnx/model.onnx` (kokorox/src/utils/hf_cache.rs:128-158; the fp16 / int8 / 4-bit
+//! variants of hf_cache.rs:135-144 load too, de-quantised).  The library reads the ONNX initialisers itself (no ONNX
+//! Runtime, no protobuf crate); a pre-converted `KXHIPW01` container (`import_onnx` below, or
+//! `python -m kokorox_amd.importer`) is recognised by its magic and skips the conversion.
 #![allow(clippy::too_many_arguments)]
 
 use ndarray::{ArrayBase, IxDyn, OwnedRepr};
@@ -41,6 +44,7 @@ pub struct KxDispatcher {
 extern "C" {
     fn kx_init(device_id: c_int, err: *mut c_char, err_len: usize) -> c_int;
     fn kx_create(weights_path: *const c_char, device_id: c_int, err: *mut c_char, err_len: usize) -> *mut KxModel;
+    fn kx_import_onnx(onnx_path: *const c_char, out_path: *const c_char, err: *mut c_char, err_len: usize) -> c_int;
     fn kx_create_from_device_blob(d_blob: *const c_void, n_bytes: usize, device_id: c_int, err: *mut c_char,
                                   err_len: usize) -> *mut KxModel;
     fn kx_create_replicas(weights_path: *const c_char, device_ids: *const c_int, n: c_int,
@@ -109,6 +113,18 @@ pub fn init(device_id: i32) -> Result<(), String> {
     }
 }
 
+/// Host only: `model.onnx` -> the KXHIPW01 container `HipKoko::new` would build from it in memory (convert once, load
+/// faster afterwards).  No reference counterpart: ONNX Runtime parses the file on every start (ort_base.rs:27-33).
+pub fn import_onnx(onnx_path: &str, out_path: &str) -> Result<(), String> {
+    let a = CString::new(onnx_path).map_err(|e| e.to_string())?;
+    let b = CString::new(out_path).map_err(|e| e.to_string())?;
+    let mut err = vec![0 as c_char; 1024];
+    match unsafe { kx_import_onnx(a.as_ptr(), b.as_ptr(), err.as_mut_ptr(), err.len()) } {
+        KX_OK => Ok(()),
+        _ => Err(cstr_buf(&err)),
+    }
+}
+
 pub fn version() -> String {
     unsafe { CStr::from_ptr(kx_version()) }.to_string_lossy().into_owned()
 }
@@ -123,6 +139,7 @@ unsafe impl Sync for HipKoko {}
 
 impl HipKoko {
     /// `OrtKoko::new` (ort_koko.rs:31-35): load failure is an `Err(String)`; the caller `.expect`s (koko.rs:572).
+    /// `model_path` is the `.onnx` the reference passes (koko.rs:570-573) or a pre-converted KXHIPW01 container.
     pub fn new(model_path: String) -> Result<Self, String> {
         Self::on_device(model_path, 0)
     }
@@ -380,8 +397,6 @@ impl Drop for HipKoko {
     }
 }
 
-/// Batching front over one model per GPU: the replacement for the reference's one-request-at-a-time
-/// `Mutex<Session>` (ort_koko.rs:78; kokorox-openai/src/lib.rs:370-439, kokorox-websocket/src/lib.rs:657-668).
 /// How a dispatched request names its voice.
 pub enum Voice<'a> {
     Row(&'a [f32]),
@@ -389,6 +404,8 @@ pub enum Voice<'a> {
     Mix(&'a [(i32, f32)]),
 }
 
+/// Batching front over one model per GPU: the replacement for the reference's one-request-at-a-time
+/// `Mutex<Session>` (ort_koko.rs:78; kokorox-openai/src/lib.rs:370-439, kokorox-websocket/src/lib.rs:657-668).
 /// `submit` blocks and may be called from any number of threads (tokio `spawn_blocking` in the servers).
 pub struct HipKokoDispatcher {
     d: *mut KxDispatcher,

@@ -9,10 +9,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libkokorox_hip.so")
-SOURCES = ["conv_mfma.hip", "conv_f16x3.hip", "conv_f16x3_da.hip", "conv_f16x3_da_p1.hip", "conv_f16x3_da_w2.hip", "conv_f16x3_da_s16.hip", "conv_f16x3_dag.hip", "kernels_misc.hip", "model.hip", "api.hip", "dispatcher.hip"]
-HEADERS = ["kx_common.h", "model.h", "kx_handle.h", "conv_epilogue.h", "conv_f16x3_common.h", os.path.join("..", "..", "include", "kokorox_hip.h")]
-# sources that include another source (the reduced-precision direct-A instantiations): rebuilt when that one changes
-EXTRA_DEPS = {"conv_f16x3_da_p1.hip": ["conv_f16x3_da.hip"], "conv_f16x3_da_w2.hip": ["conv_f16x3_da.hip"], "conv_f16x3_da_s16.hip": ["conv_f16x3_da.hip"]}
+SOURCES = ["conv_mfma.hip", "conv_f16x3.hip", "conv_f16x3_da.hip", "conv_f16x3_da_p1.hip", "conv_f16x3_da_w2.hip", "conv_f16x3_da_s16.hip", "conv_f16x3_dag.hip", "kernels_misc.hip", "model.hip", "api.hip", "dispatcher.hip", "onnx_import.cpp"]
+HEADERS = ["kx_common.h", "conv_epilogue.h", "conv_f16x3_common.h"]
+_PUB = os.path.join("..", "..", "include", "kokorox_hip.h")
+# sources that include another source (the direct-A instantiation units) or a header of their own: rebuilt when that one changes
+EXTRA_DEPS = {"model.hip": ["onnx_import.h", "model.h", _PUB], "api.hip": ["model.h", "kx_handle.h", _PUB],
+              "dispatcher.hip": ["model.h", "kx_handle.h", _PUB], "onnx_import.cpp": ["onnx_import.h"], "conv_f16x3_da_p1.hip": ["conv_f16x3_da.hip"], "conv_f16x3_da_w2.hip": ["conv_f16x3_da.hip"], "conv_f16x3_da_s16.hip": ["conv_f16x3_da.hip"]}
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-result"]
 
 
@@ -41,10 +43,12 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        o = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or not _newer(o, [s] + hdrs + [os.path.join(CSRC, d) for d in EXTRA_DEPS.get(src, [])]):
-            jobs.append([_hipcc(), *FLAGS, "-c", s, "-o", o])
+            # plain C++ sources (the ONNX reader) are host code only: no offload flag
+            flags = [f for f in FLAGS if not f.startswith("--offload-arch")] if src.endswith(".cpp") else FLAGS
+            jobs.append([_hipcc(), *flags, "-c", s, "-o", o])
             LAST_BUILD["compiled"].append(src)
         else:
             LAST_BUILD["reused"].append(src)

@@ -122,6 +122,24 @@ kx_model* kx_create(const char* weights_path, int device_id, char* err, size_t e
     return rc == KX_OK ? h : nullptr;
 }
 
+int kx_import_onnx(const char* onnx_path, const char* out_path, char* err, size_t err_len) {
+    return guarded_free(err, err_len, [&] {
+        KX_REQUIRE(onnx_path && *onnx_path && out_path && *out_path, "kx_import_onnx: two paths");
+        FILE* f = fopen(onnx_path, "rb");
+        if (!f) throw Error(KX_ERR_IO, std::string("cannot open weight file: ") + onnx_path);
+        std::vector<unsigned char> in;
+        unsigned char buf[1 << 16];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof buf, f)) > 0) in.insert(in.end(), buf, buf + got);
+        fclose(f);
+        const std::vector<unsigned char> blob = kx::import_onnx_bytes(in.data(), in.size());
+        FILE* o = fopen(out_path, "wb");
+        if (!o) throw Error(KX_ERR_IO, std::string("cannot write ") + out_path);
+        const bool ok = fwrite(blob.data(), 1, blob.size(), o) == blob.size();
+        if (fclose(o) != 0 || !ok) throw Error(KX_ERR_IO, std::string("short write on ") + out_path);
+    });
+}
+
 kx_model* kx_create_from_device_blob(const void* d_blob, size_t n_bytes, int device_id, char* err, size_t err_len) {
     kx_model* h = nullptr;
     int rc = guarded_free(err, err_len, [&] {
@@ -403,6 +421,8 @@ struct ConvTestExtra {  // epilogue forms beyond bias: residual, accumulate into
     int accum = 0;
     float out_mul = 1.f, out_div = 1.f;
     float* stats_out = nullptr;  // [B][Cout][2] = sum, sum of squares over the stored row
+    const int32_t* lens = nullptr;  // [B] valid input columns per utterance (ragged batch); null = all L
+    int pad_ld = 0;              // rows padded to a multiple of 32 floats as in the model (x padding = NaN, y padding checked)
 };
 }  // namespace
 
@@ -419,13 +439,32 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
         KX_REQUIRE(mode >= kx::CONV_F32 && mode <= kx::CONV_F16X3_DA, "test_conv1d: mode must be 0, 1, 2 or 3");
         kx::ConvArgs a{};
         a.ws_force = mode == kx::CONV_F16X3_LDS ? 1 : (mode == kx::CONV_F16X3_DA ? 2 : 0);
-        a.x = dm.up(x, (size_t)B * Cin * L);
-        a.x_bs = (long)Cin * L;
-        a.x_ld = L;
+        // row strides: the caller's dense rows, or (pad_ld) the model's: a multiple of 32 floats, input padding poisoned
+        const int x_ld = ex.pad_ld ? (L + 31) & ~31 : L, y_ld = ex.pad_ld ? (Lout + 31) & ~31 : Lout;
+        const float poison = std::nanf(""), sentinel = -12345.5f;
+        auto padded = [&](const float* src, int rows_total, int len, int ld, float fill) {
+            std::vector<float> v((size_t)rows_total * ld, fill);
+            for (int r = 0; r < rows_total; ++r) std::memcpy(&v[(size_t)r * ld], src + (size_t)r * len, (size_t)len * 4);
+            return v;
+        };
+        if (ex.pad_ld) {
+            const std::vector<float> xp = padded(x, B * Cin, L, x_ld, poison);
+            a.x = dm.up(xp.data(), xp.size());
+        } else
+            a.x = dm.up(x, (size_t)B * Cin * L);
+        a.x_bs = (long)Cin * x_ld;
+        a.x_ld = x_ld;
         a.Cin = Cin;
+        if (ex.lens) {  // ragged batch: utterance b is lens[b] columns long (stride-1 convs: the output shrinks by L - Lout)
+            KX_REQUIRE(!transposed && stride == 1, "test_conv1d: ragged lengths with stride-1 convs only");
+            for (int b = 0; b < B; ++b) {
+                KX_REQUIRE(ex.lens[b] >= 1 && ex.lens[b] <= L && ex.lens[b] + (Lout - L) >= 1, "test_conv1d: lens out of range");
+                lens[b] = ex.lens[b];
+            }
+        }
         int* d_one = dm.up(lens.data(), B);
-        a.in_len = kx::LenMap{d_one, 0, L};
-        a.out_len = kx::LenMap{d_one, 0, Lout};
+        a.in_len = ex.lens ? kx::LenMap{d_one, 1, 0} : kx::LenMap{d_one, 0, L};
+        a.out_len = ex.lens ? kx::LenMap{d_one, 1, Lout - L} : kx::LenMap{d_one, 0, Lout};
         a.n_chunks = (Cin + kx::CONV_CK - 1) / kx::CONV_CK;
         const float* dw = dm.up(w, (size_t)Cout * Cin * k);
         int BM, rows;
@@ -471,22 +510,30 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
         a.slope = slope;
         a.alpha = alpha ? dm.up(alpha, (size_t)Cin) : nullptr;
         KX_REQUIRE(act != kx::ACT_SNAKE || alpha, "test_conv1d: snake needs alpha");
-        float* dy = dm.get<float>((size_t)B * Cout * Lout);
-        if (ex.accum)
+        float* dy = dm.get<float>((size_t)B * Cout * y_ld);
+        if (ex.pad_ld) {  // y holds the running sum (accumulate) or zeros; the row padding holds a sentinel nobody may touch
+            std::vector<float> y0((size_t)B * Cout * Lout, 0.f);
+            const std::vector<float> yp = padded(ex.accum ? y : y0.data(), B * Cout, Lout, y_ld, sentinel);
+            KX_HIP(hipMemcpy(dy, yp.data(), yp.size() * 4, hipMemcpyHostToDevice));
+        } else if (ex.accum)
             KX_HIP(hipMemcpy(dy, y, (size_t)B * Cout * Lout * 4, hipMemcpyHostToDevice));  // y holds the running sum
         else
             KX_HIP(hipMemset(dy, 0, (size_t)B * Cout * Lout * 4));
         a.y = dy;
-        a.y_bs = (long)Cout * Lout;
-        a.y_ld = Lout;
+        a.y_bs = (long)Cout * y_ld;
+        a.y_ld = y_ld;
         a.out_mul = ex.out_mul;
         a.out_div = ex.out_div;
         a.accum = ex.accum;
         if (ex.resid) {
             KX_REQUIRE(!transposed, "test_conv1d: residual with the plain conv only");
-            a.resid = dm.up(ex.resid, (size_t)B * Cout * Lout);
-            a.r_bs = (long)Cout * Lout;
-            a.r_ld = Lout;
+            if (ex.pad_ld) {
+                const std::vector<float> rp = padded(ex.resid, B * Cout, Lout, y_ld, poison);
+                a.resid = dm.up(rp.data(), rp.size());
+            } else
+                a.resid = dm.up(ex.resid, (size_t)B * Cout * Lout);
+            a.r_bs = (long)Cout * y_ld;
+            a.r_ld = y_ld;
         }
         float2* d_part = nullptr;
         int cols_per_tile = 0;
@@ -526,7 +573,16 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
             kx::launch_conv1d(a, BM, B, transposed ? L + 1 : Lout, nullptr);
         }
         KX_HIP(hipDeviceSynchronize());
-        KX_HIP(hipMemcpy(y, dy, (size_t)B * Cout * Lout * 4, hipMemcpyDeviceToHost));
+        if (ex.pad_ld) {
+            std::vector<float> yp((size_t)B * Cout * y_ld);
+            KX_HIP(hipMemcpy(yp.data(), dy, yp.size() * 4, hipMemcpyDeviceToHost));
+            for (int r = 0; r < B * Cout; ++r) {
+                std::memcpy(y + (size_t)r * Lout, &yp[(size_t)r * y_ld], (size_t)Lout * 4);
+                for (int c = Lout; c < y_ld; ++c)
+                    if (yp[(size_t)r * y_ld + c] != sentinel) throw Error(KX_ERR_STATE, "test_conv1d: the kernel wrote into the row padding");
+            }
+        } else
+            KX_HIP(hipMemcpy(y, dy, (size_t)B * Cout * Lout * 4, hipMemcpyDeviceToHost));
         if (ex.stats_out) {
             std::vector<float2> part((size_t)B * rows * a.stat_tiles);
             KX_HIP(hipMemcpy(part.data(), d_part, part.size() * sizeof(float2), hipMemcpyDeviceToHost));
@@ -563,6 +619,23 @@ int kx_test_conv1d_epilogue(int device_id, const float* x, int B, int Cin, int L
     const int Lout = L + 2 * pad - dil * (k - 1);
     return test_conv1d_impl(device_id, x, B, Cin, L, w, bias, Cout, k, 1, pad, dil, 0, 0, 0.f, nullptr, nullptr, y, Lout, mode,
                             ex, err, err_len);
+}
+
+int kx_test_conv1d_full(int device_id, const float* x, int B, int Cin, int L, const int32_t* lens, int pad_ld, const float* w,
+                        const float* bias, int Cout, int k, int pad, int dil, int act, float slope, const float* alpha,
+                        const float* norm, const float* resid, int accumulate, float out_mul, float out_div, float* y,
+                        float* stats_out, int mode, char* err, size_t err_len) {
+    ConvTestExtra ex;
+    ex.resid = resid;
+    ex.accum = accumulate;
+    ex.out_mul = out_mul;
+    ex.out_div = out_div;
+    ex.stats_out = stats_out;
+    ex.lens = lens;
+    ex.pad_ld = pad_ld;
+    const int Lout = L + 2 * pad - dil * (k - 1);
+    return test_conv1d_impl(device_id, x, B, Cin, L, w, bias, Cout, k, 1, pad, dil, 0, act, slope, alpha, norm, y, Lout, mode, ex,
+                            err, err_len);
 }
 
 int kx_test_lstm(int device_id, const float* x, int B, int L, int n_in, const float* w_ih, const float* w_hh,

@@ -88,7 +88,9 @@ struct ConvOpts {
     float2* stat_part = nullptr;   // fuse InstanceNorm partial sums of the output into the epilogue
 };
 
-std::vector<unsigned char> read_weight_file(const char* path);  // whole KXHIPW01 file, header checked
+// the KXHIPW01 image behind `path`: the container itself (header checked), or built from the `.onnx` the reference passes
+std::vector<unsigned char> read_weight_file(const char* path);
+std::vector<unsigned char> import_onnx_bytes(const unsigned char* data, size_t n);  // ImportError -> Error(KX_ERR_IO)
 
 class Model {
   public:

@@ -3,8 +3,13 @@
 // the published Kokoro-82M; stage comments name the upstream module.
 #include "model.h"
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cstdlib>
 #include <cstring>
+
+#include "onnx_import.h"
 
 namespace kx {
 
@@ -95,36 +100,69 @@ static size_t check_header(const unsigned char* h, size_t have) {
     return (size_t)total;
 }
 
-std::vector<unsigned char> read_weight_file(const char* path) {
-    KX_REQUIRE(path && *path, "kx_create: empty weights path");
+static std::vector<unsigned char> read_all(const char* path, const char* what) {
     FILE* f = fopen(path, "rb");
-    if (!f) throw Error(2, std::string("cannot open weight file: ") + path);
+    if (!f) throw Error(2, std::string("cannot open ") + what + ": " + path);
     fseek(f, 0, SEEK_END);
-    const size_t n = (size_t)ftell(f);
+    const long sz = ftell(f);
     fseek(f, 0, SEEK_SET);
-    std::vector<unsigned char> host(n);
-    const size_t got = fread(host.data(), 1, n, f);
+    if (sz < 0) {
+        fclose(f);
+        throw Error(2, std::string("cannot size ") + what + ": " + path);
+    }
+    std::vector<unsigned char> host((size_t)sz);
+    const size_t got = host.empty() ? 0 : fread(host.data(), 1, host.size(), f);
     fclose(f);
-    if (got != n) throw Error(2, std::string("short read on weight file: ") + path);
-    const size_t total = check_header(host.data(), n);
-    if (total != n) throw Error(2, "weight blob: file size does not match header");
+    if (got != host.size()) throw Error(2, std::string("short read on ") + what + ": " + path);
     return host;
 }
 
-void Model::load_file(const char* path) {
+std::vector<unsigned char> import_onnx_bytes(const unsigned char* data, size_t n) {
+    try {
+        return onnx_to_kxw(data, n);
+    } catch (const ImportError& e) {
+        throw Error(2, std::string("weight file is not a KXHIPW01 blob (bad magic) and not a readable ONNX model: ") + e.what());
+    }
+}
+
+// The KXHIPW01 image behind `path`.  The path is either the library's own container or — what the reference passes to
+// OrtKoko::new (koko.rs:570-573, hf_cache.rs:128-158) — the `.onnx` file, which is converted in memory
+// (onnx_import.cpp).  `<path>.kxw` beside an .onnx is used instead when it is at least as new as the .onnx and whole;
+// it is written only when KOKOROX_KXW_CACHE=1 (a library should not drop files into a model cache unasked).
+std::vector<unsigned char> read_weight_file(const char* path) {
     KX_REQUIRE(path && *path, "kx_create: empty weights path");
-    FILE* f = fopen(path, "rb");
-    if (!f) throw Error(2, std::string("cannot open weight file: ") + path);
-    fseek(f, 0, SEEK_END);
-    const size_t n = (size_t)ftell(f);
-    fseek(f, 0, SEEK_SET);
-    std::vector<unsigned char> host(n);
-    const size_t got = fread(host.data(), 1, n, f);
-    fclose(f);
-    if (got != n) throw Error(2, std::string("short read on weight file: ") + path);
-    const size_t total = check_header(host.data(), n);
-    if (total != n) throw Error(2, "weight blob: file size does not match header");
-    parse_table(host.data(), n, total, table_);
+    std::vector<unsigned char> host = read_all(path, "weight file");
+    if (is_kxw_magic(host.data(), host.size())) {
+        const size_t total = check_header(host.data(), host.size());
+        if (total != host.size()) throw Error(2, "weight blob: file size does not match header");
+        return host;
+    }
+    const std::string cache = std::string(path) + ".kxw";
+    struct stat so, sc;
+    if (stat(path, &so) == 0 && stat(cache.c_str(), &sc) == 0 && sc.st_mtime >= so.st_mtime) {
+        try {
+            std::vector<unsigned char> c = read_all(cache.c_str(), "weight cache");
+            if (is_kxw_magic(c.data(), c.size()) && check_header(c.data(), c.size()) == c.size()) return c;
+        } catch (const Error&) {  // an unreadable cache is not an error: convert again
+        }
+    }
+    std::vector<unsigned char> blob = import_onnx_bytes(host.data(), host.size());
+    if (const char* e = getenv("KOKOROX_KXW_CACHE")) {
+        if (strcmp(e, "1") == 0) {
+            const std::string tmp = cache + ".tmp." + std::to_string((long)getpid());
+            if (FILE* f = fopen(tmp.c_str(), "wb")) {
+                const bool ok = fwrite(blob.data(), 1, blob.size(), f) == blob.size();
+                if (fclose(f) != 0 || !ok || rename(tmp.c_str(), cache.c_str()) != 0) (void)remove(tmp.c_str());
+            }
+        }
+    }
+    return blob;
+}
+
+void Model::load_file(const char* path) {
+    const std::vector<unsigned char> host = read_weight_file(path);
+    const size_t n = host.size();
+    parse_table(host.data(), n, n, table_);
     KX_HIP(hipSetDevice(device));
     KX_HIP(hipMalloc((void**)&blob_, n));
     blob_bytes_ = n;

@@ -21,6 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libkokorox_hip.so")
 
 PACK_F32_MONO, PACK_F32_STEREO, PACK_PCM16_MONO = 0, 1, 2
+KX_OK, KX_ERR_INVALID, KX_ERR_IO, KX_ERR_DEVICE, KX_ERR_STATE = 0, 1, 2, 3, 4  # include/kokorox_hip.h
 KX_FLAG_NOISE_OFF = 1
 KX_FLAG_TAPS = 2
 STYLE_DIM = 256
@@ -69,6 +70,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_version": (cp, []),
         "kx_init": (i32, [i32, cp, sz]),
         "kx_create": (vp, [cp, i32, cp, sz]),
+        "kx_import_onnx": (i32, [cp, cp, cp, sz]),
         "kx_create_from_device_blob": (vp, [vp, sz, i32, cp, sz]),
         "kx_destroy": (None, [vp]),
         "kx_last_error": (cp, [vp]),
@@ -107,6 +109,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_debug_tap": (i32, [vp, cp, i32, vp, i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "kx_test_conv1d": (i32, [i32, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp,
                                  i32, i32, cp, sz]),
+        "kx_test_conv1d_full": (i32, [i32, vp, i32, i32, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, i32, f32,
+                                      f32, vp, vp, i32, cp, sz]),
         "kx_test_lstm": (i32, [i32, vp, i32, i32, i32] + [vp] * 9 + [cp, sz]),
         "kx_test_source": (i32, [i32, vp, i32, i32, vp, f32, u64, u64, i32, vp, cp, sz]),
         "kx_test_attention": (i32, [i32, vp, vp, i32, i32, vp, cp, sz]),
@@ -124,13 +128,13 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 
 ABI_SYMBOLS = [
-    "kx_version", "kx_init", "kx_create", "kx_create_from_device_blob", "kx_create_replicas", "kx_destroy",
+    "kx_version", "kx_init", "kx_create", "kx_import_onnx", "kx_create_from_device_blob", "kx_create_replicas", "kx_destroy",
     "kx_last_error", "kx_last_error_copy", "kx_infer",
     "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_set_utterance_base", "kx_set_lanes",
     "kx_set_conv_mode", "kx_get_conv_mode", "kx_set_stft_variant", "kx_get_stft_variant",
     "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_profile_aux", "kx_diag_enable", "kx_diag_count", "kx_diag_get", "kx_set_act_prescale", "kx_set_voice_table", "kx_infer_voices",
     "kx_infer_packed", "kx_free_packed", "kx_dispatcher_create", "kx_dispatcher_submit", "kx_dispatcher_submit_ex", "kx_dispatcher_model_batches",
-    "kx_dispatcher_stats", "kx_dispatcher_destroy", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test_attention", "kx_test_conv1d_epilogue", "kx_test_lstm_fault",
+    "kx_dispatcher_stats", "kx_dispatcher_destroy", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test_attention", "kx_test_conv1d_epilogue", "kx_test_conv1d_full", "kx_test_lstm_fault",
 ]
 
 
@@ -483,6 +487,17 @@ class Dispatcher:
 
 
 # ---- stand-alone kernel hooks (tests) -----------------------------------------------------
+def import_onnx(onnx_path: str, out_path: str) -> str:
+    """`model.onnx` -> KXHIPW01 container through the LIBRARY's own reader (csrc/onnx_import.cpp; host only, no GPU):
+    what kx_create does in memory when it is handed the .onnx path the reference passes (koko.rs:570-573)."""
+    lib = load_library()
+    err = C.create_string_buffer(2048)
+    rc = lib.kx_import_onnx(os.fsencode(onnx_path), os.fsencode(out_path), err, len(err))
+    if rc != KX_OK:
+        raise KokoroxHipError(rc, err.value.decode(errors="replace"))
+    return out_path
+
+
 def _err_call(fn, *args):
     err = C.create_string_buffer(512)
     rc = fn(*args, err, len(err))
@@ -529,6 +544,24 @@ def conv1d_epilogue(x, w, bias=None, pad=0, dil=1, resid=None, y_init=None, out_
     st = np.zeros((B, Cout, 2), dtype=np.float32) if want_stats else None
     _err_call(lib.kx_test_conv1d_epilogue, device, _ptr(x), B, Cin, L, _ptr(w), _ptr(_f32(bias)), Cout, k, pad, dil,
               _ptr(_f32(resid)), 0 if y_init is None else 1, float(out_mul), float(out_div), _ptr(y), _ptr(st), mode)
+    return (y, st) if want_stats else y
+
+
+def conv1d_full(x, w, bias=None, pad=0, dil=1, act=0, slope=0.0, alpha=None, norm=None, resid=None, y_init=None,
+                out_mul=1.0, out_div=1.0, want_stats=False, lens=None, pad_ld=False, mode=1, device=0):
+    """Stride-1 conv with the fused input transform (AdaIN affine + leaky / snake) AND the epilogue forms, on a ragged
+    batch (lens[b] valid input columns) and, with pad_ld, on the model's padded rows.  Returns y or (y, stats[B,Cout,2])."""
+    lib = load_library()
+    x, w = _f32(x), _f32(w)
+    B, Cin, L = x.shape
+    Cout, _, k = w.shape
+    Lout = L + 2 * pad - dil * (k - 1)
+    y = np.zeros((B, Cout, Lout), dtype=np.float32) if y_init is None else _f32(y_init).copy()
+    st = np.zeros((B, Cout, 2), dtype=np.float32) if want_stats else None
+    ln = None if lens is None else np.ascontiguousarray(lens, dtype=np.int32)
+    _err_call(lib.kx_test_conv1d_full, device, _ptr(x), B, Cin, L, _ptr(ln), 1 if pad_ld else 0, _ptr(w), _ptr(_f32(bias)),
+              Cout, k, pad, dil, act, float(slope), _ptr(_f32(alpha)), _ptr(_f32(norm)), _ptr(_f32(resid)),
+              0 if y_init is None else 1, float(out_mul), float(out_div), _ptr(y), _ptr(st), mode)
     return (y, st) if want_stats else y
 
 

@@ -87,7 +87,10 @@ def fold_weight_norm(flat: Mapping[str, np.ndarray]) -> "OrderedDict[str, np.nda
             raise ValueError(f"incomplete weight-norm pair for {base}")
         v = gv["v"].astype(np.float64)
         g = gv["g"].astype(np.float64)
-        norm = np.sqrt((v.reshape(v.shape[0], -1) ** 2).sum(axis=1)).reshape((-1,) + (1,) * (v.ndim - 1))
+        # summed in index order (cumsum is strictly sequential; .sum() is pairwise): the in-library reader
+        # (csrc/onnx_import.cpp) adds the squares in the same order, so both write the same bytes
+        ss = np.cumsum(v.reshape(v.shape[0], -1) ** 2, axis=1)[:, -1]
+        norm = np.sqrt(ss).reshape((-1,) + (1,) * (v.ndim - 1))
         out[base + ".weight"] = (g * v / norm).astype(np.float32)
     return out
 
@@ -291,7 +294,8 @@ def onnx_to_state_dict(path: str):
                 tgt = spec_name(path, "weight")
                 if a is not None and tgt:
                     place(tgt, a, "conv node")
-            if len(n.inputs) > 2 and n.inputs[2] and canonical(n.inputs[2]) is None:
+            # (ConvInteger's third input is the activation zero point, not a bias)
+            if op != "ConvInteger" and len(n.inputs) > 2 and n.inputs[2] and canonical(n.inputs[2]) is None:
                 b = const(n.inputs[2])
                 tgt = spec_name(path, "bias")
                 if b is not None and tgt:

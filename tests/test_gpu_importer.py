@@ -71,3 +71,110 @@ def test_imported_onnx_blob_runs_and_matches_the_oracle(hip_model, blob_path, tm
             assert out.shape != ref.shape or np.abs(out - ref).max() > 1e-3
     finally:
         m.close()
+
+
+# ---- kx_create / kx_create_replicas handed the .onnx itself (what OrtKoko::new receives, koko.rs:570-573) --------------
+def _write_onnx(synth, path, style):
+    from kokorox_amd import onnx_lite as OX
+    C = _dresser()
+    nodes, inits = C._dress_as_export({k: np.asarray(v) for k, v in synth.items()}, style)
+    with open(path, "wb") as f:
+        f.write(OX.model_bytes(nodes, inits))
+
+
+def _fnv1a(a: np.ndarray) -> int:
+    h = 1469598103934665603
+    for byte in a.astype("<f4").tobytes():
+        h ^= byte
+        h = (h * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.mark.parametrize("style", ["fp32", "int8", "q4"])
+def test_kx_create_opens_the_onnx_file_itself(blob_path, golden, tmp_path, style):
+    """`HipKoko::new(model_path)` with the path the reference passes: the library's own ONNX reader (csrc/onnx_import.cpp)
+    must give the waveform of the Python-imported .kxw route bit for bit, from ctypes and from compiled C++."""
+    import subprocess
+    from kokorox_amd import hip_koko as hk
+    from kokorox_amd import importer as I
+    from kokorox_amd import weights as W
+    from oracle import kokoro_ref as R
+    src = str(tmp_path / f"model_{style}.onnx")
+    _write_onnx(W.read_blob(blob_path), src, style)
+    kxw = str(tmp_path / f"model_{style}.python.kxw")
+    I.import_checkpoint(src, kxw)
+    ids = R.synthetic_inputs(1, 16, seed=77)[0]
+    style_row = W.synthetic_voices(1)[0, 16, 0]
+    m_py = hk.HipKoko.new(kxw)
+    try:
+        ref = m_py.infer([list(ids)], [list(style_row)], 1.0, seed=6)
+        g = golden["hello_world"]
+        ref_g = m_py.infer([list(g["ids"])], [list(g["style"])], 1.0, seed=2)
+    finally:
+        m_py.close()
+    m = hk.HipKoko.new(src)  # the .onnx path, as koko.rs:570-573 passes it
+    try:
+        out = m.infer([list(ids)], [list(style_row)], 1.0, seed=6)
+    finally:
+        m.close()
+    np.testing.assert_array_equal(out, ref)
+    assert not os.path.exists(src + ".kxw"), "no cache file may appear unasked"
+    # compiled C++ host on the same .onnx
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "kokorox_amd", "lib")
+    exe = str(tmp_path / "hipkoko_demo")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "cpp", "hipkoko_demo.cpp"), "-L", lib_dir, "-lkokorox_hip",
+                    f"-Wl,-rpath,{lib_dir}", "-o", exe], check=True)
+    srow = str(tmp_path / "style.f32")
+    g["style"].astype("<f4").tofile(srow)
+    r = subprocess.run([exe, src, srow], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert f"samples={ref_g.shape[0]} fnv1a={_fnv1a(ref_g):016x}" in r.stdout
+
+
+def test_onnx_cache_replicas_and_error_paths(blob_path, tmp_path, monkeypatch):
+    from kokorox_amd import hip_koko as hk
+    from kokorox_amd import weights as W
+    from oracle import kokoro_ref as R
+    src = str(tmp_path / "model.onnx")
+    _write_onnx(W.read_blob(blob_path), src, "fp32")
+    ids = R.synthetic_inputs(1, 12, seed=5)[0]
+    style_row = W.synthetic_voices(1)[0, 12, 0]
+    # replicas from the .onnx: one read + one conversion, two models
+    ms = hk.HipKoko.replicas(src, [0, 0])
+    try:
+        a = ms[0].infer([list(ids)], [list(style_row)], 1.0, seed=1)
+        b = ms[1].infer([list(ids)], [list(style_row)], 1.0, seed=1)
+    finally:
+        for m in ms:
+            m.close()
+    np.testing.assert_array_equal(a, b)
+    # opt-in cache: written beside the .onnx, then used (a cache that is older than the .onnx is ignored)
+    monkeypatch.setenv("KOKOROX_KXW_CACHE", "1")
+    m = hk.HipKoko.new(src)
+    m.close()
+    cache = src + ".kxw"
+    assert os.path.exists(cache)
+    monkeypatch.delenv("KOKOROX_KXW_CACHE")
+    py = str(tmp_path / "py.kxw")
+    from kokorox_amd import importer as I
+    I.import_onnx(src, py)
+    assert open(cache, "rb").read() == open(py, "rb").read()
+    # poison the .onnx but keep it older than the cache: the cache is what loads
+    onnx_bytes = open(src, "rb").read()
+    t = os.path.getmtime(cache)
+    with open(src, "wb") as f:
+        f.write(onnx_bytes[: len(onnx_bytes) // 3])
+    os.utime(src, (t - 10, t - 10))
+    m = hk.HipKoko.new(src)
+    try:
+        np.testing.assert_array_equal(m.infer([list(ids)], [list(style_row)], 1.0, seed=1), a)
+    finally:
+        m.close()
+    # a newer (still truncated) .onnx invalidates the cache: KX_ERR_IO class failure, message from the reader
+    os.utime(src, (t + 10, t + 10))
+    with pytest.raises(RuntimeError, match="not a readable ONNX model.*truncated"):
+        hk.HipKoko.new(src)
+    with pytest.raises(RuntimeError, match="not a readable ONNX model"):
+        hk.HipKoko.replicas(src, [0, 0])

@@ -212,7 +212,9 @@ def test_attention_matches_float64_softmax(T, lens):
 
 def _sweep_cases(n, seed):
     """Random conv shapes concentrated on tile borders: columns around multiples of 128 / 256, output channels
-    around the 32 / 64 / 128-row tiles, every kernel width and dilation the graph uses."""
+    around the 32 / 64 / 128-row tiles, every kernel width and dilation the graph uses, with and without the fused
+    AdaIN affine + leaky / snake input transform (act 2 with k = 11 and an even number of 16-channel chunks is the
+    16x16x32 form of the direct-A kernel, conv16_da_s16_shape)."""
     rng = np.random.default_rng(seed)
     cases = []
     for _ in range(n):
@@ -224,25 +226,148 @@ def _sweep_cases(n, seed):
         Cin = int(rng.choice([3, 16, 17, 48, 96, 130]))
         B = int(rng.integers(1, 4))
         pad = (k - 1) * d // 2
-        cases.append((B, Cin, Cout, L, k, pad, d))
+        act = int(rng.choice([0, 0, 1, 2]))
+        cases.append((B, Cin, Cout, L, k, pad, d, act))
+    # the S16 form's own borders (k = 11 snake, Cin 17..32 / 49..64 / whole chunks, rows around the 128-row tile)
+    for Cin, Cout, L, d in ((24, 130, 191, 1), (32, 128, 193, 3), (56, 256, 257, 5), (128, 127, 385, 1), (96, 129, 63, 3)):
+        cases.append((2, Cin, Cout, L, 11, 5 * d, d, 2))
     return cases
 
 
-@pytest.mark.parametrize("B,Cin,Cout,L,k,p,d", _sweep_cases(36, seed=2024))
-def test_conv1d_tile_border_sweep(B, Cin, Cout, L, k, p, d):
+def _act_ref(x, act, norm, alpha, slope=0.2):
+    """float64 reference of the fused input transform: AdaIN affine, then leaky / snake (x [B,Cin,L] torch f64)."""
+    if act == 0:
+        return x
+    n = torch.from_numpy(norm).double()
+    xt = (x - n[0][:, :, None]) * n[1][:, :, None] + n[2][:, :, None]
+    if act == 2:
+        a = torch.from_numpy(alpha).double()[None, :, None]
+        return xt + (1 / a) * torch.sin(a * xt) ** 2
+    return F.leaky_relu(xt, slope)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,L,k,p,d,act", _sweep_cases(36, seed=2024))
+def test_conv1d_tile_border_sweep(B, Cin, Cout, L, k, p, d, act):
     """Both contraction modes must agree with float64 at every tile border (full / edge epilogue forms, the
-    128- and 256-column tiles, the small-grid 4x1 tiles, virtual taps for k = 1)."""
+    128- and 256-column tiles, the small-grid 4x1 tiles, virtual taps for k = 1, the 16x16x32 form's 128- and
+    192-column tiles through modes 1 and 3)."""
     from kokorox_amd import hip_koko as hk
     rng = np.random.default_rng(B * 7919 + Cin * 131 + Cout * 17 + L + k)
     x = rng.standard_normal((B, Cin, L), dtype=np.float32)
     w = (rng.standard_normal((Cout, Cin, k), dtype=np.float32) / np.sqrt(Cin * k)).astype(np.float32)
     b = rng.standard_normal(Cout, dtype=np.float32)
-    ref = F.conv1d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
-                   padding=p, dilation=d).numpy()
-    for mode in (1, 0, 2):
-        y = hk.conv1d(x, w, b, pad=p, dil=d, mode=mode)
+    norm = rng.standard_normal((3, B, Cin), dtype=np.float32)
+    norm[1] = 1.0 + 0.2 * norm[1]
+    alpha = (rng.random(Cin, dtype=np.float32) + 0.5).astype(np.float32)
+    kw = dict(act=act, slope=0.2, alpha=alpha, norm=norm) if act else dict()
+    ref = F.conv1d(_act_ref(torch.from_numpy(x).double(), act, norm, alpha), torch.from_numpy(w).double(),
+                   torch.from_numpy(b).double(), padding=p, dilation=d).numpy()
+    tol = 3e-5 if act else 2e-5
+    for mode in (1, 0, 2, 3):
+        y = hk.conv1d(x, w, b, pad=p, dil=d, mode=mode, **kw)
         assert y.shape == ref.shape
-        assert np.abs(y - ref).max() < 2e-5, (mode, np.abs(y - ref).max())
+        assert np.abs(y - ref).max() < tol, (mode, np.abs(y - ref).max())
+
+
+def _s16_border_cases():
+    """The 16x16x32 form's predicate (conv_f16x3_da.hip, conv16_da_s16_shape: snake, 11 taps, (k-1) dil <= 64, an even
+    number >= 2 of 16-channel chunks, 128-row weight tiles) admits partial chunks (Cin 17..32, 49..64), Cout != n 128 and
+    any length: every (Cin, Cout) pair of the lists below meets every length once over the three dilations."""
+    cins, couts, lens, dils = [24, 32, 56, 128], [22, 128, 130, 256], [1, 63, 65, 191, 193, 257, 517], [1, 3, 5]
+    cases, i = [], 0
+    for ci in cins:
+        for co in couts:
+            for L in lens:
+                cases.append((ci, co, L, dils[i % 3], bool(i & 1)))
+                i += 1
+    return cases
+
+
+@pytest.mark.parametrize("Cin,Cout,L,d,pad_ld", _s16_border_cases())
+def test_s16_form_borders_against_float64(Cin, Cout, L, d, pad_ld):
+    """act = 2, k = 11 through the full hook (fused transform + every epilogue form the generator uses + ragged lengths +
+    the model's padded rows), against torch float64, in hook mode 1 (small grid: the form's 128-column tile) and mode 3
+    (its 192-column tile).  Cout = 22 takes a 32-row weight tile, i.e. NOT this form: it rides along as the control."""
+    from kokorox_amd import hip_koko as hk
+    rng = np.random.default_rng(Cin * 1000003 + Cout * 1009 + L * 7 + d)
+    B, k = 3, 11
+    p = 5 * d
+    lens = np.array([L, max(1, (2 * L) // 3), max(1, L // 3)], dtype=np.int32)
+    x = rng.standard_normal((B, Cin, L), dtype=np.float32)
+    w = (rng.standard_normal((Cout, Cin, k), dtype=np.float32) / np.sqrt(Cin * k)).astype(np.float32)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    norm = rng.standard_normal((3, B, Cin), dtype=np.float32)
+    norm[1] = 1.0 + 0.2 * norm[1]
+    alpha = (rng.random(Cin, dtype=np.float32) + 0.5).astype(np.float32)
+    res = rng.standard_normal((B, Cout, L), dtype=np.float32)
+    run = rng.standard_normal((B, Cout, L), dtype=np.float32)
+    xt = _act_ref(torch.from_numpy(x).double(), 2, norm, alpha)
+    conv = np.zeros((B, Cout, L))
+    for i in range(B):  # each utterance is convolved alone over its own length (zero padding at ITS end)
+        n = int(lens[i])
+        conv[i, :, :n] = F.conv1d(xt[i:i + 1, :, :n], torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                                  padding=p, dilation=d).numpy()[0]
+    valid = np.arange(L)[None, None, :] < lens[:, None, None]
+    kw = dict(pad=p, dil=d, act=2, alpha=alpha, norm=norm, lens=lens, pad_ld=pad_ld)
+    mul = float(np.float32(0.70710678))
+    for mode in (1, 3):
+        # (1) plain store; columns past an utterance's length are not written
+        y = hk.conv1d_full(x, w, b, mode=mode, **kw)
+        assert np.abs(np.where(valid, y - conv, 0.0)).max() < 3e-5, mode
+        assert np.all(np.where(valid, 0.0, y) == 0.0), mode
+        # (2) residual + fused statistics (64-column slots in this form), over each utterance's own columns
+        y, st = hk.conv1d_full(x, w, b, resid=res, want_stats=True, mode=mode, **kw)
+        ref = np.where(valid, conv + res, 0.0)
+        assert np.abs(np.where(valid, y - ref, 0.0)).max() < 3e-5, mode
+        y64 = np.where(valid, y.astype(np.float64), 0.0)
+        assert np.abs(st[..., 0] - y64.sum(axis=2)).max() < 2e-3 * max(1.0, np.sqrt(L) / 10), mode
+        assert np.abs(st[..., 1] - (y64 * y64).sum(axis=2)).max() < 1e-5 * max(1.0, (y64 * y64).sum(axis=2).max()), mode
+        # (3) residual + accumulate into the running sum, mean over three (the AdaINResBlock1 tail)
+        y = hk.conv1d_full(x, w, b, resid=res, y_init=run, out_div=3.0, mode=mode, **kw)
+        ref = (conv + res + run) / 3.0
+        assert np.abs(np.where(valid, y - ref, 0.0)).max() < 3e-5, mode
+        assert np.array_equal(np.where(valid, 0.0, y), np.where(valid, 0.0, run)), mode  # the rest of the running sum stays
+        # (4) output scale + statistics
+        y, st = hk.conv1d_full(x, w, b, out_mul=mul, want_stats=True, mode=mode, **kw)
+        assert np.abs(np.where(valid, y - conv * mul, 0.0)).max() < 3e-5, mode
+        y64 = np.where(valid, y.astype(np.float64), 0.0)
+        assert np.abs(st[..., 0] - y64.sum(axis=2)).max() < 2e-3 * max(1.0, np.sqrt(L) / 10), mode
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("k,d,act,Cin,Cout,L", [(3, 1, 1, 40, 130, 300), (7, 3, 2, 48, 128, 517), (11, 5, 2, 64, 256, 700),
+                                               (5, 1, 0, 130, 64, 129), (3, 5, 2, 128, 128, 1025), (7, 1, 2, 20, 22, 513)])
+def test_full_hook_ragged_padded_every_mode(k, d, act, Cin, Cout, L, mode):
+    """The ragged / padded-row / fused-transform + epilogue combination on the OTHER kernel forms (f32 MFMA, LDS-DMA,
+    direct-A 32x32x16): what the generator's resblocks launch, against float64."""
+    from kokorox_amd import hip_koko as hk
+    rng = np.random.default_rng(k * 100 + L)
+    B = 3
+    p = d * (k - 1) // 2
+    lens = np.array([max(1, L // 2), L, max(1, L - 37)], dtype=np.int32)
+    x = rng.standard_normal((B, Cin, L), dtype=np.float32)
+    w = (rng.standard_normal((Cout, Cin, k), dtype=np.float32) / np.sqrt(Cin * k)).astype(np.float32)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    norm = rng.standard_normal((3, B, Cin), dtype=np.float32)
+    norm[1] = 1.0 + 0.2 * norm[1]
+    alpha = (rng.random(Cin, dtype=np.float32) + 0.5).astype(np.float32)
+    res = rng.standard_normal((B, Cout, L), dtype=np.float32)
+    xt = _act_ref(torch.from_numpy(x).double(), act, norm, alpha)
+    conv = np.zeros((B, Cout, L))
+    for i in range(B):
+        n = int(lens[i])
+        conv[i, :, :n] = F.conv1d(xt[i:i + 1, :, :n], torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                                  padding=p, dilation=d).numpy()[0]
+    valid = np.arange(L)[None, None, :] < lens[:, None, None]
+    kw = dict(pad=p, dil=d, act=act, slope=0.2, lens=lens, pad_ld=True)
+    if act:
+        kw.update(alpha=alpha, norm=norm)
+    y, st = hk.conv1d_full(x, w, b, resid=res, want_stats=True, mode=mode, **kw)
+    assert np.abs(np.where(valid, y - (conv + res), 0.0)).max() < 3e-5
+    assert np.all(np.where(valid, 0.0, y) == 0.0)
+    y64 = np.where(valid, y.astype(np.float64), 0.0)
+    assert np.abs(st[..., 0] - y64.sum(axis=2)).max() < 2e-3 * max(1.0, np.sqrt(L) / 10)
+    assert np.abs(st[..., 1] - (y64 * y64).sum(axis=2)).max() < 1e-5 * max(1.0, (y64 * y64).sum(axis=2).max())
 
 
 EPI_CASES = [

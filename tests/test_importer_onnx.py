@@ -23,7 +23,7 @@ def _torch_to_onnx_gates(a, hid=256):
     return np.concatenate([i, o, f, g], axis=0)
 
 
-def _dress_as_export(tensors, style="fp32", rng=None):
+def _dress_as_export(tensors, style="fp32", rng=None, pooler=768):
     """state-dict tensors -> (node bytes list, initializer bytes list) of an exporter-looking graph."""
     rng = rng or np.random.default_rng(0)
     nodes, inits = [], []
@@ -43,7 +43,7 @@ def _dress_as_export(tensors, style="fp32", rng=None):
     done = set()
     # LSTMs first (four tensors per direction)
     for name in spec:
-        if name.endswith(".weight_ih_l0"):
+        if name.endswith(".weight_ih_l0") and name in tensors:  # (a caller may dress a subset of the model)
             base = name[: -len(".weight_ih_l0")]
             Wi = np.stack([_torch_to_onnx_gates(tensors[f"{base}.weight_ih_l0{s}"]) for s in ("", "_reverse")])
             R = np.stack([_torch_to_onnx_gates(tensors[f"{base}.weight_hh_l0{s}"]) for s in ("", "_reverse")])
@@ -148,7 +148,7 @@ def _dress_as_export(tensors, style="fp32", rng=None):
         done.add(name)
     # things a real file also holds and the importer must ignore
     add_init("bert.embeddings.position_ids", np.arange(512, dtype=np.int64)[None])
-    add_init("bert.pooler.weight", np.zeros((768, 768), np.float32))
+    add_init("bert.pooler.weight", np.zeros((pooler, pooler), np.float32))
     return nodes, inits
 
 
