@@ -227,7 +227,14 @@ void kx_free_packed(void* p);
  * kokorox-openai/src/lib.rs:370-439, kokorox-websocket/src/lib.rs:657-668).  Any number of threads submit
  * single utterances; one worker per model (= per GPU) coalesces whatever is queued — up to max_batch, waiting
  * at most max_wait_us after the first arrival — into one batched forward.  A request's waveform depends only
- * on (ids, style, speed, seed), not on what it was batched with. */
+ * on (ids, style, speed, seed), not on what it was batched with, nor on which model ran it — with one exception: a model
+ * whose two-CU LSTM recurrence ever timed out (a KX_ERR_DEVICE failure naming the LSTM) runs the one-CU recurrence from
+ * then on, whose sums are added in another order, so ITS results agree with the other models' to rounding only (and, past
+ * the harmonic-phase integration, in form only).
+ * A request is checked completely when it is submitted (token ids and count, speed, format, voice ids against the smallest
+ * voice table among the models, mix size) and refused there with KX_ERR_INVALID: a bad request never reaches a batch.
+ * If a batch still fails as a whole, an INVALID-class failure is re-run request by request (only the requests that fail
+ * alone report it) and a DEVICE-class failure is retried once as a batch, then reported by every request of it. */
 typedef struct kx_dispatcher kx_dispatcher;
 kx_dispatcher* kx_dispatcher_create(kx_model** models, int n_models, int max_batch, int max_wait_us, char* err,
                                     size_t err_len);
@@ -305,7 +312,8 @@ int kx_test_source(int device_id, const float* f0, int B, int F2, const float* l
 /* Fault injection for the two-CU LSTM recurrence (process-wide, test only): nth > 0 makes the nth following launch of
  * the pair kernel, and every later one, lose the second half of each pair and poll with a short limit, so the call it
  * belongs to must fail with KX_ERR_DEVICE (the bounded wait's error path) and the model must fall back to the one-CU
- * kernel; 0 switches it off.  nth = 6 hits the frame-axis LSTM of a forward, after the mid-way error check. */
+ * kernel; 0 switches it off.  nth = 6 hits the frame-axis LSTM of a forward, after the mid-way error check.
+ * Arms only in a process whose environment has KX_TEST_HOOKS=1 (KX_ERR_STATE otherwise). */
 int kx_test_lstm_fault(int nth);
 
 const char* kx_version(void);

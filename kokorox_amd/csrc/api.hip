@@ -12,63 +12,10 @@ using kx::Model;
 
 #include "kx_handle.h"
 
-static void set_err(char* err, size_t n, const std::string& msg) {
-    if (err && n) {
-        strncpy(err, msg.c_str(), n - 1);
-        err[n - 1] = 0;
-    }
-}
-
-// The message of a failed call belongs to the THREAD that made the call (several threads may share one model: the Rust
-// handle is Send + Sync): it is kept per thread, set by that thread's own failure and cleared by its own next success on
-// the same model, so another thread's calls can neither blank it nor replace it.
-static thread_local std::string tls_last_error;
-static thread_local const void* tls_last_error_model = nullptr;
-
-static void note_error(const kx_model* h, const std::string& msg) {
-    tls_last_error = msg;
-    tls_last_error_model = h;
-}
-
-template <class F>
-static int guarded(kx_model* h, F&& f) {
-    if (!h || !h->m) return KX_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(h->m->mu);
-    try {
-        f(*h->m);
-        if (tls_last_error_model == h) {
-            tls_last_error.clear();
-            tls_last_error_model = nullptr;
-        }
-        return KX_OK;
-    } catch (const Error& e) {
-        note_error(h, e.what());
-        return e.code;
-    } catch (const std::exception& e) {
-        note_error(h, e.what());
-        return KX_ERR_DEVICE;
-    } catch (...) {
-        note_error(h, "unknown failure");
-        return KX_ERR_DEVICE;
-    }
-}
-
-template <class F>
-static int guarded_free(char* err, size_t n, F&& f) {
-    try {
-        f();
-        return KX_OK;
-    } catch (const Error& e) {
-        set_err(err, n, e.what());
-        return e.code;
-    } catch (const std::exception& e) {
-        set_err(err, n, e.what());
-        return KX_ERR_DEVICE;
-    } catch (...) {
-        set_err(err, n, "unknown failure");
-        return KX_ERR_DEVICE;
-    }
-}
+#include "api_guard.h"  // the exception fence + the per-thread last-error text (HIP-free: sanitizer-tested on the CPU)
+using kx::guarded;
+using kx::guarded_free;
+using kx::set_err;
 
 static void check_device(int device_id) {
     int n = 0;
@@ -229,7 +176,7 @@ void kx_destroy(kx_model* m) {
 // the same model afterwards cannot change or free what this pointer refers to.
 const char* kx_last_error(const kx_model* m) {
     if (!m || !m->m) return "null model";
-    return tls_last_error_model == m ? tls_last_error.c_str() : "";  // (the calling thread's own last failure on this model)
+    return kx::last_error_of(m);  // (the calling thread's own last failure on this model)
 }
 
 int kx_last_error_copy(const kx_model* m, char* buf, size_t buf_len) {
@@ -238,7 +185,7 @@ int kx_last_error_copy(const kx_model* m, char* buf, size_t buf_len) {
         set_err(buf, buf_len, "null model");
         return KX_ERR_INVALID;
     }
-    set_err(buf, buf_len, tls_last_error_model == m ? tls_last_error : std::string());
+    set_err(buf, buf_len, kx::last_error_of(m));
     return KX_OK;
 }
 
@@ -284,6 +231,7 @@ int kx_infer_device(kx_model* m, const int64_t* d_ids, int64_t t_stride, const i
                     const float* d_styles, const float* speeds_host, int n_speed, uint64_t seed, uint32_t flags,
                     float* d_audio, int64_t audio_ld, int32_t* d_frames, int64_t* need_ld) {
     return guarded(m, [&](Model& M) {
+        M.order_after_null_stream();  // (the caller's device inputs: typically written on the legacy null stream)
         M.infer_device(d_ids, t_stride, lens_host, B, d_styles, speeds_host, n_speed, seed, flags, d_audio, audio_ld,
                        d_frames, need_ld);
     });
@@ -320,6 +268,9 @@ int kx_set_stft_variant(kx_model* m, int variant) {
 int kx_get_stft_variant(kx_model* m) { return (m && m->m) ? m->m->stft_variant : -1; }
 
 int kx_test_lstm_fault(int nth) {
+    // fault injection is a process-wide switch: it arms only when the environment says this is a test process
+    const char* e = getenv("KX_TEST_HOOKS");
+    if (!e || strcmp(e, "1") != 0) return KX_ERR_STATE;
     kx::lstm_set_test_fault(nth);
     return KX_OK;
 }

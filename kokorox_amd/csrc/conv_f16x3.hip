@@ -374,21 +374,24 @@ static int env_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-int conv16_cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
+int conv16_cu_count() {  // of the CURRENT device (cached per device: models on several GPUs launch from several threads)
+    static std::atomic<int> n[KX_MAX_DEVICES];
+    int dev = 0;
+    KX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= KX_MAX_DEVICES) return 256;
+    int v = n[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
         hipDeviceProp_t pr;
-        KX_HIP(hipGetDevice(&dev));
         KX_HIP(hipGetDeviceProperties(&pr, dev));
-        n = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+        v = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+        n[dev].store(v, std::memory_order_relaxed);
     }
-    return n;
+    return v;
 }
 
 template <int BM, int BN, int WM, int WN, int ACT, int TK, bool PF, int VT = 1>
 static void launch_inst16_pf(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
-    static size_t lds_limit = 64 * 1024;  // raise the dynamic-LDS limit only as far as a launch needs
+    static DynLdsLimit lds_limit;  // raise the dynamic-LDS limit only as far as a launch needs (per device)
     auto kern = conv1d_f16x3_kernel<BM, BN, WM, WN, ACT, TK, PF, VT>;
     const int XW = (BN - 1) * a.stride + (a.K - 1) * a.dil + 1;
     const int XWp = PF ? ((VT > 1) ? 128 : BN + 128) : ((XW + 3) & ~3);  // (as in the kernel)
@@ -398,10 +401,7 @@ static void launch_inst16_pf(const ConvArgs& a, int B, int max_cols, hipStream_t
     if (lds + lds_pad <= 160 * 1024) lds += lds_pad;
     KX_REQUIRE(lds <= 160 * 1024, "conv1d f16x3: LDS tile too large for this k/stride");
     KX_REQUIRE(VT == 1 || (a.K == 1 && a.stride == 1 && XW <= 128), "conv1d f16x3: virtual taps need a k=1 GEMM");
-    if (lds > lds_limit) {
-        KX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_limit = lds;
-    }
+    lds_limit.ensure(reinterpret_cast<const void*>(kern), lds);
     dim3 grid((max_cols + BN - 1) / BN, (a.Cout + BM - 1) / BM, a.merge_T > 0 ? 1 : B);
     KX_REQUIRE(grid.x > 0 && grid.y > 0 && grid.y < 65536 && B > 0 && B < 65536, "conv1d f16x3: bad grid");
     KX_REQUIRE(a.merge_T == 0 || (PF && a.K == 1 && a.stride == 1 && a.pad == 0 && !a.in_up2 && !a.nmean &&

@@ -150,16 +150,13 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a) {
 
 template <int BM, int BN, int WM, int WN>
 static void launch_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
-    static size_t lds_limit = 64 * 1024;  // raise the dynamic-LDS limit only as far as a launch needs
+    static DynLdsLimit lds_limit;  // raise the dynamic-LDS limit only as far as a launch needs (per device)
     auto kern = conv1d_mfma_kernel<BM, BN, WM, WN>;
     const int XW = (BN - 1) * a.stride + (a.K - 1) * a.dil + 1;
     const int XWp = (XW + 3) & ~3;
     const size_t lds = sizeof(float) * ((size_t)a.K * CONV_CK * BM + (size_t)CONV_CK * XWp);
     KX_REQUIRE(lds <= 160 * 1024, "conv1d: LDS tile too large for this k/stride");
-    if (lds > lds_limit) {
-        KX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_limit = lds;
-    }
+    lds_limit.ensure(reinterpret_cast<const void*>(kern), lds);
     dim3 grid((max_cols + BN - 1) / BN, (a.Cout + BM - 1) / BM, B);
     KX_REQUIRE(grid.x > 0 && grid.y > 0 && grid.y < 65536 && B > 0 && B < 65536, "conv1d: bad grid");
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);

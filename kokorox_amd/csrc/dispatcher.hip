@@ -1,128 +1,20 @@
-// Request dispatcher: coalesces concurrent single-utterance requests into batched forwards and spreads a waiting
-// queue over the idle GPUs.
+// Request dispatcher: the C entry points and the kx::Model backend of the host logic in dispatcher_core.h (queue, workers,
+// shares, submit-time validation, error policy — HIP-free there so that the CPU suite can run it under the thread and
+// address sanitizers against a stub model).
 //
 // The reference serves every request through one `Mutex<Session>` (kokorox/src/onn/ort_koko.rs:78; callers
 // kokorox-openai/src/lib.rs:370-439, kokorox-websocket/src/lib.rs:657-668): N clients = N sequential runs.
-// Here any number of OS threads call kx_dispatcher_submit*(); one worker thread per model (= per GPU) takes requests
-// off ONE shared queue and runs them as one batched forward:
-//   * a worker that finds work waits at most `max_wait_us` after the oldest request's arrival for company (unless the
-//     queue already holds a full batch for every idle worker), then takes its SHARE of the queue: ceil(queued / idle
-//     workers), at most `max_batch`.  32 requests waiting in front of 8 idle GPUs become 8 batches of 4, not one batch
-//     of 32 on one GPU beside seven idle ones; a single worker that frees up while the others are busy takes up to a
-//     whole batch (the reference's config 5: kokorox-openai, 32 clients over 8 GPUs).
-//   * a request names its voice either as the 256-float style row (what `mix_styles` returns, koko.rs:1255-1306) or as
-//     (voice id, weight) pairs into the device voice table (kx_set_voice_table on every model), single voice or mix,
-//     and its output form (f32 mono / f32 stereo, koko.rs:1239-1246 / PCM16, kokorox-websocket/src/lib.rs:696-736);
-//     requests of every kind share one batch (per-utterance kinds / formats in Model::HostCall).
-//   * every request carries its own noise seed, applied per utterance, so a request's bytes are identical whether it
-//     ran alone or inside any batch on any of the models (tests/test_gpu_dispatcher.py).
-//   * errors are per request: if a batch fails as a whole, its requests are re-run one by one and only the ones that
-//     fail alone report the error.
-#include <chrono>
-#include <condition_variable>
-#include <deque>
-#include <cstring>
-#include <thread>
-
-#include "../../include/kokorox_hip.h"
+#include "dispatcher_core.h"
 #include "kx_handle.h"
 
 namespace {
 
-constexpr int MAX_MIX = 16;
+using kx::dispatch::Request;
 
-struct Request {
-    std::vector<int64_t> ids;
-    int kind = 0;  // 0 = style row, 1 = single voice, 2 = mix
-    std::vector<float> style;
-    int32_t voice_ids[MAX_MIX];
-    float weights[MAX_MIX];
-    int n_mix = 0;
-    int format = 0;
-    float speed = 1.f;
-    uint64_t seed = 0;
-    // result
-    void* out = nullptr;
-    int64_t out_bytes = 0, out_samples = 0;
-    int rc = -1;
-    std::string err;
-    bool done = false;
-    std::chrono::steady_clock::time_point t_submit;
-};
-
-}  // namespace
-
-struct kx_dispatcher {
-    std::vector<kx_model*> models;
-    int max_batch = 64;
-    int max_wait_us = 2000;
-    std::mutex mu;
-    std::condition_variable cv_work, cv_done;
-    std::deque<Request*> queue;
-    bool stop = false;
-    int idle = 0;  // workers waiting for work (or for company) right now
-    std::vector<std::thread> workers;
-    int64_t n_requests = 0, n_batches = 0, max_seen_batch = 0, n_retried = 0;
-    std::vector<int64_t> per_model_batches;
-
-    void worker(int wi) {
-        kx_model* h = models[wi];
-        for (;;) {
-            std::vector<Request*> batch;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                ++idle;
-                cv_work.wait(lk, [&] { return stop || !queue.empty(); });
-                if (stop && queue.empty()) {
-                    --idle;
-                    return;
-                }
-                // work is here: give others a short chance to join, unless every idle worker already has a full batch
-                while (!stop && !queue.empty() && (long)queue.size() < (long)max_batch * idle) {
-                    const auto deadline = queue.front()->t_submit + std::chrono::microseconds(max_wait_us);
-                    if (std::chrono::steady_clock::now() >= deadline) break;
-                    cv_work.wait_until(lk, deadline);
-                }
-                // this worker's share of what is waiting (the other idle workers wake up on the same notify and take theirs)
-                long take = ((long)queue.size() + idle - 1) / idle;
-                take = take > max_batch ? max_batch : take;
-                --idle;
-                while (!queue.empty() && (long)batch.size() < take) {
-                    batch.push_back(queue.front());
-                    queue.pop_front();
-                }
-                if (batch.empty()) continue;  // (another worker was quicker)
-                n_batches += 1;
-                per_model_batches[wi] += 1;
-                n_requests += (int64_t)batch.size();
-                if ((int64_t)batch.size() > max_seen_batch) max_seen_batch = (int64_t)batch.size();
-            }
-            if (!queue_empty_hint()) cv_work.notify_all();  // (what is left is for the other idle workers)
-            const int rc = run_batch(h, batch);
-            if (rc != KX_OK && batch.size() > 1) {
-                // per-request isolation: the batch failed as a whole; only the requests that fail alone report it
-                {
-                    std::lock_guard<std::mutex> lk(mu);
-                    n_retried += (int64_t)batch.size();
-                }
-                for (Request* r : batch) {
-                    std::vector<Request*> one{r};
-                    run_batch(h, one);
-                }
-            }
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                for (Request* r : batch) r->done = true;
-            }
-            cv_done.notify_all();
-        }
-    }
-
-    bool queue_empty_hint() {
-        std::lock_guard<std::mutex> lk(mu);
-        return queue.empty();
-    }
-
+// One batched forward on a model: requests of every kind / format in one HostCall (per-utterance kinds, formats, keys).
+struct ModelBackend {
+    using Handle = kx_model;
+    static int n_voices(kx_model* h) { return h->m->n_voices(); }
     static int run_batch(kx_model* h, std::vector<Request*>& batch) {
         const int B = (int)batch.size();
         size_t stride = 0;
@@ -203,45 +95,13 @@ struct kx_dispatcher {
         kx::host_out_free(out);  // (the batch buffer is one of the pooled page-locked ones)
         return rc;
     }
-
-    // common tail of the submit calls: queue the request, wait for its result
-    int submit(Request& r, void** out, int64_t* out_bytes, int64_t* out_samples, char* err, size_t err_len) {
-        r.t_submit = std::chrono::steady_clock::now();
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            if (stop) {
-                if (err && err_len) snprintf(err, err_len, "dispatcher is shutting down");
-                return KX_ERR_STATE;
-            }
-            queue.push_back(&r);
-            cv_work.notify_all();
-            cv_done.wait(lk, [&] { return r.done; });
-        }
-        if (r.rc != KX_OK) {
-            if (err && err_len) snprintf(err, err_len, "%s", r.err.c_str());
-            free(r.out);
-            return r.rc;
-        }
-        *out = r.out;
-        if (out_bytes) *out_bytes = r.out_bytes;
-        if (out_samples) *out_samples = r.out_samples;
-        return KX_OK;
-    }
 };
 
-static bool check_common(kx_dispatcher* d, const int64_t* ids, int n_tokens, float speed, int format, const char* who,
-                         char* err, size_t err_len) {
-    if (!d || !ids || n_tokens < 1 || n_tokens > KX_MAX_TOKENS || !(speed > 0.f) || format < 0 || format > 2) {
-        if (err && err_len) snprintf(err, err_len, "%s: bad argument (1..512 tokens, speed > 0, format 0..2)", who);
-        return false;
-    }
-    for (int t = 0; t < n_tokens; ++t)
-        if (ids[t] < 0 || ids[t] >= 178) {
-            if (err && err_len) snprintf(err, err_len, "%s: token id outside 0..177", who);
-            return false;
-        }
-    return true;
-}
+}  // namespace
+
+struct kx_dispatcher : kx::dispatch::Core<ModelBackend> {
+    kx_dispatcher(kx_model** ms, int n, int max_b, int wait_us) : kx::dispatch::Core<ModelBackend>(ms, n, max_b, wait_us) {}
+};
 
 extern "C" {
 
@@ -252,72 +112,36 @@ kx_dispatcher* kx_dispatcher_create(kx_model** models, int n_models, int max_bat
         return nullptr;
     }
     for (int i = 0; i < n_models; ++i)
-        if (!models[i]) {
+        if (!models[i] || !models[i]->m) {
             if (err && err_len) snprintf(err, err_len, "dispatcher: null model");
             return nullptr;
         }
-    kx_dispatcher* d = new kx_dispatcher();
-    d->models.assign(models, models + n_models);
-    d->max_batch = max_batch;
-    d->max_wait_us = max_wait_us;
-    d->per_model_batches.assign(n_models, 0);
-    for (int i = 0; i < n_models; ++i) d->workers.emplace_back([d, i] { d->worker(i); });
-    return d;
+    try {
+        return new kx_dispatcher(models, n_models, max_batch, max_wait_us);
+    } catch (const std::exception& e) {
+        if (err && err_len) snprintf(err, err_len, "dispatcher: %s", e.what());
+        return nullptr;
+    }
 }
 
 int kx_dispatcher_submit(kx_dispatcher* d, const int64_t* ids, int n_tokens, const float* style, float speed,
                          uint64_t seed, float** out, int64_t* out_len, char* err, size_t err_len) {
-    if (!style || !out || !out_len) {
-        if (err && err_len) snprintf(err, err_len, "dispatcher_submit: bad argument (1..512 tokens, speed > 0)");
+    if (!d) {
+        if (err && err_len) snprintf(err, err_len, "dispatcher_submit: null dispatcher");
         return KX_ERR_INVALID;
     }
-    if (!check_common(d, ids, n_tokens, speed, 0, "dispatcher_submit", err, err_len)) return KX_ERR_INVALID;
-    Request r;
-    r.ids.assign(ids, ids + n_tokens);
-    r.style.assign(style, style + KX_STYLE_DIM);
-    r.speed = speed;
-    r.seed = seed;
-    void* p = nullptr;
-    const int rc = d->submit(r, &p, nullptr, out_len, err, err_len);
-    if (rc == KX_OK) *out = static_cast<float*>(p);
-    return rc;
+    return d->submit_row(ids, n_tokens, style, speed, seed, out, out_len, err, err_len);
 }
 
 int kx_dispatcher_submit_ex(kx_dispatcher* d, const int64_t* ids, int n_tokens, const float* style,
                             const int32_t* voice_ids, const float* weights, int n_mix, float speed, uint64_t seed,
                             int format, void** out, int64_t* out_bytes, int64_t* out_samples, char* err, size_t err_len) {
-    if (!out || !out_bytes || !out_samples) {
-        if (err && err_len) snprintf(err, err_len, "dispatcher_submit_ex: null output argument");
+    if (!d) {
+        if (err && err_len) snprintf(err, err_len, "dispatcher_submit_ex: null dispatcher");
         return KX_ERR_INVALID;
     }
-    if (!check_common(d, ids, n_tokens, speed, format, "dispatcher_submit_ex", err, err_len)) return KX_ERR_INVALID;
-    Request r;
-    if (style) {
-        if (voice_ids) {
-            if (err && err_len) snprintf(err, err_len, "dispatcher_submit_ex: give the style row OR voice ids, not both");
-            return KX_ERR_INVALID;
-        }
-        r.kind = 0;
-        r.style.assign(style, style + KX_STYLE_DIM);
-    } else {
-        if (!voice_ids || n_mix < 1 || n_mix > MAX_MIX || n_tokens < 2 || (!weights && n_mix != 1)) {
-            if (err && err_len)
-                snprintf(err, err_len, "dispatcher_submit_ex: voices need 1..16 ids (one id when weights is null: a single "
-                                       "voice) and the two 0 pads among the tokens");
-            return KX_ERR_INVALID;
-        }
-        r.kind = weights ? 2 : 1;
-        r.n_mix = n_mix;
-        for (int k = 0; k < n_mix; ++k) {
-            r.voice_ids[k] = voice_ids[k];
-            r.weights[k] = weights ? weights[k] : 0.f;
-        }
-    }
-    r.ids.assign(ids, ids + n_tokens);
-    r.format = format;
-    r.speed = speed;
-    r.seed = seed;
-    return d->submit(r, out, out_bytes, out_samples, err, err_len);
+    return d->submit_ex(ids, n_tokens, style, voice_ids, weights, n_mix, speed, seed, format, out, out_bytes, out_samples, err,
+                        err_len);
 }
 
 int kx_dispatcher_stats(kx_dispatcher* d, int64_t* n_requests, int64_t* n_batches, int64_t* max_batch_seen) {
@@ -338,12 +162,7 @@ int kx_dispatcher_model_batches(kx_dispatcher* d, int64_t* per_model, int n_mode
 
 void kx_dispatcher_destroy(kx_dispatcher* d) {
     if (!d) return;
-    {
-        std::lock_guard<std::mutex> lk(d->mu);
-        d->stop = true;
-    }
-    d->cv_work.notify_all();
-    for (std::thread& t : d->workers) t.join();
+    d->shutdown();  // serves what is queued, refuses new submits, waits for every client thread to leave
     delete d;
 }
 

@@ -722,12 +722,8 @@ void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, floa
     static_assert(LSTM_LDS_K % 4 == 0 && LSTM_REG_K % 4 == 0, "whole float4 groups of h");
     if (lstm_use_pair() && xchg && err_word) {
         const size_t lds = sizeof(float) * (256 + 512 + 4 + (size_t)LSTMP_LDS * 1024 * 4);
-        static bool pair_attr = false;
-        if (!pair_attr) {
-            KX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_pair_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            pair_attr = true;
-        }
+        static DynLdsLimit pair_limit;  // (per device: each GPU's model launches from its own host thread)
+        pair_limit.ensure(reinterpret_cast<const void*>(lstm_pair_kernel), lds);
         // The tag's epoch is 16 bits wide and counted PER exchange buffer (epoch_state; the test hook's one-shot buffer has
         // none): when it wraps the buffer is cleared in stream order, so a granule of 65535 launches ago can never carry
         // the tag of a live step.  (0 is what a cleared buffer holds and is never used as an epoch.)
@@ -755,12 +751,8 @@ void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, floa
         return;
     }
     const size_t lds = sizeof(float) * (256 + 1024 + (size_t)LSTM_LDS_K * 1024);
-    static bool attr_set = false;
-    if (!attr_set) {
-        KX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-        attr_set = true;
-    }
+    static DynLdsLimit one_limit;
+    one_limit.ensure(reinterpret_cast<const void*>(lstm_kernel), lds);
     hipLaunchKernelGGL(lstm_kernel, dim3(B, 2), dim3(1024), lds, s, gx, gx_bs, gx_ld, whhT, y, y_bs, y_ld, len);
     KX_HIP(hipGetLastError());
 }

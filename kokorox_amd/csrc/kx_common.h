@@ -9,11 +9,34 @@
 #include <stdexcept>
 #include <string>
 
+#include <atomic>
+#include <mutex>
+
+#include "kx_error.h"
+
 namespace kx {
 
-struct Error : std::runtime_error {
-    int code;
-    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+constexpr int KX_MAX_DEVICES = 64;
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel, and a process may hold one model per GPU,
+// each driven from a host thread of its own (kx_create_replicas, the dispatcher's workers): one of these per launcher
+// (function-local static), raised per device only as far as a launch needs, race-free.
+struct DynLdsLimit {
+    std::atomic<size_t> limit[KX_MAX_DEVICES];
+    std::mutex mu;
+    DynLdsLimit() {
+        for (auto& l : limit) l.store(64 * 1024);  // what a kernel may use without the attribute
+    }
+    void ensure(const void* kern, size_t lds) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= KX_MAX_DEVICES) throw Error(3, "dynamic LDS limit: bad current device");
+        if (lds <= limit[dev].load(std::memory_order_acquire)) return;
+        std::lock_guard<std::mutex> lk(mu);
+        if (lds <= limit[dev].load(std::memory_order_relaxed)) return;
+        const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) throw Error(3, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
+        limit[dev].store(lds, std::memory_order_release);
+    }
 };
 
 #define KX_HIP(expr)                                                                       \

@@ -1,5 +1,6 @@
 // Host-side model object behind the C ABI (include/kokorox_hip.h).
 #pragma once
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -124,7 +125,9 @@ class Model {
                        int n_speed, uint64_t seed, uint32_t flags, const HostCall& hc, void** out, int64_t* out_bytes,
                        int64_t* out_samples);
     void set_voice_table(const float* table, int n_voices);
+    int n_voices() const { return n_voices_.load(std::memory_order_acquire); }  // (read by the dispatcher without the mutex)
     void sync();
+    void order_after_null_stream();
     void set_pinned(const int32_t* pattern, int n);
     void profile_enable(bool on);
     void profile_read(int64_t* launches, double* ms, double* flops);
@@ -208,7 +211,7 @@ class Model {
     Arena arenaT_, arenaF_, arenaIO_;
     const uint64_t* d_utt_seeds_ = nullptr;  // per-utterance noise keys of the running call (dispatcher)
     float* d_voices_ = nullptr;  // [n_voices_][511][256]
-    int n_voices_ = 0;
+    std::atomic<int> n_voices_{0};
     int* d_pinned_ = nullptr;
     Arena* stats_arena_ = nullptr;  // where stats() keeps the raw sums of tensors it had to read (frame-axis arena)
     int n_pinned_ = 0;
@@ -227,6 +230,11 @@ class Model {
     std::vector<long> h_off_;          // host staging that asynchronous copies read / write: outlives the calling frame
     unsigned h_bad_id_ = 0;
     unsigned* d_dev_err_ = nullptr;
+    unsigned* h_words_ = nullptr;    // page-locked: [0] the device error word as read back
+    int* h_stage_ = nullptr;         // page-locked scratch of the small per-call host arrays (stage_ints)
+    size_t h_stage_cap_ = 0;
+    int* stage_ints(size_t n);
+    hipEvent_t ev_null_ = nullptr;   // orders kx_infer_device's inputs after the caller's null-stream work
     hipStream_t main_stream_ = nullptr;
     void check_dev_err();
     unsigned* d_bad_id_ = nullptr;  // sticky word: first out-of-table token id seen by the embedding kernels

@@ -23,10 +23,18 @@ Model::Model(int dev) : device(dev) {
         conv_mode = (strcmp(e, "f32") == 0) ? CONV_F32 : (strcmp(e, "f16") == 0 ? CONV_F16 : CONV_F16X3);
     if (const char* e = getenv("KOKOROX_STFT")) stft_variant = (strcmp(e, "torch") == 0) ? STFT_TORCH : STFT_ONNX;
     KX_HIP(hipSetDevice(device));
-    KX_HIP(hipStreamCreate(&stream_));
+    // Non-blocking: the model's streams never synchronise with the legacy null stream, so nothing one model does can stall
+    // another model on the same GPU (two models per GPU in the server, kx_create_replicas with repeated ids).  Everything
+    // on the forward's path is issued on stream_ or ordered to it by events; kx_infer_device orders its device inputs
+    // after the caller's null-stream work explicitly (infer_device_after_null).
+    KX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     main_stream_ = stream_;
     KX_HIP(hipMalloc((void**)&d_dev_err_, sizeof(unsigned)));
-    KX_HIP(hipMemset(d_dev_err_, 0, sizeof(unsigned)));
+    KX_HIP(hipMemsetAsync(d_dev_err_, 0, sizeof(unsigned), stream_));
+    KX_HIP(hipHostMalloc((void**)&h_words_, 8 * sizeof(unsigned), hipHostMallocDefault));
+    memset(h_words_, 0, 8 * sizeof(unsigned));
+    KX_HIP(hipEventCreateWithFlags(&ev_null_, hipEventDisableTiming));
+    KX_HIP(hipStreamSynchronize(stream_));
     KX_HIP(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
     lanes_[0].stream = stream_;
     for (int i = 1; i < N_LANES; ++i) KX_HIP(hipStreamCreateWithFlags(&lanes_[i].stream, hipStreamNonBlocking));
@@ -48,6 +56,9 @@ Model::~Model() {
     for (hipEvent_t e : lane_ev_) (void)hipEventDestroy(e);
     for (void* p : owned_) (void)hipFree(p);
     if (d_dev_err_) (void)hipFree(d_dev_err_);
+    if (h_words_) (void)hipHostFree(h_words_);
+    if (h_stage_) (void)hipHostFree(h_stage_);
+    if (ev_null_) (void)hipEventDestroy(ev_null_);
     for (auto* p : d_xchg_)
         if (p) (void)hipFree(p);
     for (Arena* a : {&arenaT_, &arenaF_, &arenaIO_})
@@ -190,6 +201,7 @@ void Model::load_device_blob(const void* d_blob, size_t n, bool adopt) {
     } else {
         KX_HIP(hipMalloc((void**)&blob_, n));
         KX_HIP(hipMemcpy(blob_, d_blob, n, hipMemcpyDeviceToDevice));
+        KX_HIP(hipStreamSynchronize(nullptr));  // (a device-to-device hipMemcpy may return before it has run)
     }
     build();
 }
@@ -801,10 +813,14 @@ void Model::sync() {
 
 // (the stream is idle) raise what a kernel recorded in the sticky device error word, and clear it
 void Model::check_dev_err() {
-    unsigned e = 0;
-    KX_HIP(hipMemcpy(&e, d_dev_err_, sizeof(unsigned), hipMemcpyDeviceToHost));
+    // (through the model's own stream into page-locked memory: a null-stream copy here would wait for, and hold up, every
+    // other model's blocking work on this GPU)
+    KX_HIP(hipMemcpyAsync(&h_words_[0], d_dev_err_, sizeof(unsigned), hipMemcpyDeviceToHost, main_stream_));
+    KX_HIP(hipStreamSynchronize(main_stream_));
+    const unsigned e = h_words_[0];
     if (!e) return;
-    KX_HIP(hipMemset(d_dev_err_, 0, sizeof(unsigned)));
+    KX_HIP(hipMemsetAsync(d_dev_err_, 0, sizeof(unsigned), main_stream_));
+    KX_HIP(hipStreamSynchronize(main_stream_));
     lstm_pair_ok_ = false;
     throw Error(3, "device error word " + std::to_string(e) +
                        ": a half of the two-CU LSTM recurrence never saw its partner; this call failed, the model uses the "
@@ -835,7 +851,10 @@ void Model::diag_enable(bool on) {
         diag_cap_ = 1024;
         d_diag_ = dev_alloc(3 * diag_cap_);
     }
-    if (on) KX_HIP(hipMemset(d_diag_, 0, 3 * diag_cap_ * sizeof(float)));
+    if (on) {
+        KX_HIP(hipMemsetAsync(d_diag_, 0, 3 * diag_cap_ * sizeof(float), stream_));
+        KX_HIP(hipStreamSynchronize(stream_));
+    }
 }
 
 const std::vector<Model::DiagRec>& Model::diag_collect() {
@@ -953,7 +972,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
             if (p) KX_HIP(hipFree(p));
             p = nullptr;
             KX_HIP(hipMalloc((void**)&p, lstm_exchange_bytes(B)));
-            KX_HIP(hipMemset(p, 0, lstm_exchange_bytes(B)));
+            KX_HIP(hipMemsetAsync(p, 0, lstm_exchange_bytes(B), stream_));  // (stream-ordered before the first recurrence)
         }
         xchg_cap_ = lstm_exchange_bytes(B);
         xchg_epoch_[0] = xchg_epoch_[1] = 0;
@@ -1324,6 +1343,29 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     }
 }
 
+// page-locked scratch for the small per-call host arrays (grown when a larger batch arrives; the stream is idle then: a
+// call's copies out of it are followed by that call's synchronisations)
+int* Model::stage_ints(size_t n) {
+    if (n > h_stage_cap_) {
+        KX_HIP(hipStreamSynchronize(stream_));
+        if (h_stage_) KX_HIP(hipHostFree(h_stage_));
+        h_stage_ = nullptr;
+        h_stage_cap_ = 0;
+        const size_t want = n < 1024 ? 1024 : 2 * n;
+        KX_HIP(hipHostMalloc((void**)&h_stage_, want * sizeof(int), hipHostMallocDefault));
+        h_stage_cap_ = want;
+    }
+    return h_stage_;
+}
+
+// kx_infer_device: d_ids / d_styles were written by the caller, typically on the legacy null stream (torch's default);
+// the model's stream is non-blocking, so that order is made explicit here (an event on the null stream, no host wait).
+void Model::order_after_null_stream() {
+    KX_HIP(hipSetDevice(device));
+    KX_HIP(hipEventRecord(ev_null_, nullptr));
+    KX_HIP(hipStreamWaitEvent(stream_, ev_null_, 0));
+}
+
 void Model::set_voice_table(const float* table, int n_voices) {
     KX_REQUIRE(table && n_voices >= 1 && n_voices <= 4096, "voice table: 1..4096 voices of [511][256] floats");
     KX_HIP(hipSetDevice(device));
@@ -1340,7 +1382,7 @@ void Model::set_voice_table(const float* table, int n_voices) {
     const size_t n = (size_t)n_voices * 511 * 256;
     d_voices_ = dev_alloc(n);
     KX_HIP(hipMemcpy(d_voices_, table, n * sizeof(float), hipMemcpyHostToDevice));
-    n_voices_ = n_voices;
+    n_voices_.store(n_voices, std::memory_order_release);
 }
 
 void Model::infer_host(const int64_t* ids, int64_t t_stride, const int32_t* lens, int B, const float* styles,
@@ -1444,8 +1486,13 @@ void Model::infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* l
             for (int b = 0; b < B; ++b) rows[b] = lens[b] >= 2 ? lens[b] - 2 : 0;  // tokens before the 0 padding (koko.rs:1161-1166)
             KX_HIP(hipMemcpyAsync(d_vid, hc.voice_ids, (size_t)B * mm * 4, hipMemcpyHostToDevice, stream_));
             KX_HIP(hipMemcpyAsync(d_w, hc.weights, (size_t)B * mm * 4, hipMemcpyHostToDevice, stream_));
-            KX_HIP(hipMemcpy(d_rows, rows.data(), (size_t)B * 4, hipMemcpyHostToDevice));
-            if (hc.kinds) KX_HIP(hipMemcpy(d_kinds, hc.kinds, (size_t)B * 4, hipMemcpyHostToDevice));
+            int* st = stage_ints((size_t)3 * B);  // page-locked: rows | kinds | formats, copied on the model's own stream
+            memcpy(st, rows.data(), (size_t)B * 4);
+            KX_HIP(hipMemcpyAsync(d_rows, st, (size_t)B * 4, hipMemcpyHostToDevice, stream_));
+            if (hc.kinds) {
+                memcpy(st + B, hc.kinds, (size_t)B * 4);
+                KX_HIP(hipMemcpyAsync(d_kinds, st + B, (size_t)B * 4, hipMemcpyHostToDevice, stream_));
+            }
             launch_style_mix(d_voices_, n_voices_, d_vid, d_w, mm, d_rows, hc.kinds ? d_kinds : nullptr, d_styles, B, stream_);
         }
         d_utt_seeds_ = nullptr;
@@ -1475,7 +1522,11 @@ void Model::infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* l
             total += out_bytes[b];
         }
         KX_HIP(hipMemcpyAsync(d_off, off.data(), (size_t)B * 8, hipMemcpyHostToDevice, stream_));
-        if (hc.formats) KX_HIP(hipMemcpy(d_formats, hc.formats, (size_t)B * 4, hipMemcpyHostToDevice));
+        if (hc.formats) {
+            int* st = stage_ints((size_t)3 * B) + 2 * (size_t)B;
+            memcpy(st, hc.formats, (size_t)B * 4);
+            KX_HIP(hipMemcpyAsync(d_formats, st, (size_t)B * 4, hipMemcpyHostToDevice, stream_));
+        }
         launch_pack_audio(d_audio, ld, dF_, B, Fmax_, hc.format, d_packed, 0, d_off, stream_, hc.formats ? d_formats : nullptr);
         char* host = static_cast<char*>(host_out_alloc((size_t)(total > 0 ? total : 1)));
         hipError_t e = hipMemcpyAsync(host, d_packed, (size_t)total, hipMemcpyDeviceToHost, stream_);

@@ -139,6 +139,7 @@ def test_32_clients_mixed_voices_and_formats_over_two_models(blob_path, hip_mode
     # error isolation: a request that is wrong on its own fails alone; the dispatcher keeps serving
     with pytest.raises(hk.KokoroxHipError, match="voice id"):
         d.submit_ex(reqs[(0, 0)][0], voices=99, seed=1)
+    assert d.stats()["requests"] == st["requests"], "a bad voice id is refused at submit: it must never reach a batch"
     again = d.submit_ex(reqs[(0, 0)][0], voices=reqs[(0, 0)][3], seed=reqs[(0, 0)][6], fmt=reqs[(0, 0)][5])
     d.close()
     assert not errs, errs
