@@ -66,6 +66,16 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+def dtype_label(conv_mode: int) -> str:
+    """kx_get_conv_mode: 0 f32 MFMA, 1 f16x3 split MFMA (default), 4 reduced precision (KOKOROX_CONV=f16)."""
+    if conv_mode == 1:
+        return "f32 (f16x3 split MFMA: 3 f16 MFMAs per product on hi/lo halves, f32 accumulate)"
+    if conv_mode == 4:
+        return ("f16 operands, f32 accumulate (KOKOROX_CONV=f16: one f16 MFMA per product in the decoder / generator convs; "
+                "NARROWER than the reference's fp32 -- not the headline mode)")
+    return "f32"
+
+
 def pmc_traffic(B, T, F, mode):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/*pmc_conv_traffic.json, written by tools/summarize_pmc.py for this same workload);
@@ -93,7 +103,9 @@ def roofline(f16x3, conv_flops, conv_ms, n_launch, steps, wall, B, T, F, conv_by
         return None
     ach = conv_flops / (conv_ms * 1e-3) / 1e12
     peak = PEAK_F16_MFMA_TFLOPS if f16x3 else PEAK_F32_MFMA_TFLOPS
-    kern = ("kx::conv1d_f16x3_da_kernel<ACT,K> + kx::conv1d_f16x3_kernel<128,..> (the 128-row f16x3 conv family: f16 32x32x16 MFMA x3, implicit GEMM)" if f16x3
+    kern = ("kx::conv1d_f16x3_da_kernel<ACT,K,NT,P1,W2,S16> + kx::conv1d_f16x3_dag_kernel + kx::conv1d_f16x3_kernel<128,..> (the 128-row "
+            "f16x3 conv family, implicit GEMM, 3 f16 MFMAs per product: v_mfma_f32_32x32x16_f16, and v_mfma_f32_16x16x32_f16 "
+            "in the S16 form that carries the 11-tap convs)" if f16x3
             else "kx::conv1d_mfma_kernel<128,128,2,2> (f32 32x32x2 MFMA implicit GEMM)")
     traffic, traffic_src = pmc_traffic(B, T, F, "f16x3" if f16x3 else "f32")
     alg_bytes = conv_bytes / max(n_launch, 1)
@@ -142,36 +154,63 @@ def cpu_baseline(blob_path: str, n_utts: int, n_phonemes: int, pinned):
             "utt_per_s": n_utts / wall}
 
 
-def serve_leg(models, n_clients=32, per_client=4, max_batch=64, max_wait_us=3000):
-    """BASELINE configs[4] (kokorox-openai/src/lib.rs:370-439): concurrent clients with mixed voices, incl. the mix
-    "af_sky.4+af_nicole.5" named into the device voice table, over one dispatcher in front of `models` (one per GPU).
-    Returns p50 / p99 latency, aggregate RTF and the batch statistics."""
-    import threading
-    from kokorox_amd import hip_koko as hk
+def _serve_setup(models):
     from kokorox_amd import weights as W
     tab = W.synthetic_voices(4)  # af_sky, af_nicole, am_adam, bf_emma
     for m in models:
         m.set_pinned_durations(None)
         m.set_utterance_base(0)
         m.set_voice_table(tab)
-    rules = [0, 1, [(0, 4.0), (1, 5.0)], 2, [(3, 7.0), (0, 3.0)]]
+    # three single voices, "af_sky.4+af_nicole.5" and "bf_emma.7+af_sky.3" (mix_styles, koko.rs:1255-1306)
+    return [0, 1, [(0, 4.0), (1, 5.0)], 2, [(3, 7.0), (0, 3.0)]]
+
+
+def _lat_summary(lat, audio, wall):
+    lat = np.sort(np.asarray(lat))
+    n = len(lat)
+    return {"requests": int(n), "wall_s": wall, "audio_s": float(np.sum(audio)), "aggregate_rtf": float(np.sum(audio) / wall),
+            "requests_per_s": n / wall, "latency_p50_ms": float(lat[n // 2] * 1e3),
+            "latency_p99_ms": float(lat[min(n - 1, int(n * 0.99))] * 1e3), "latency_max_ms": float(lat[-1] * 1e3)}
+
+
+def serve_leg(models, n_clients=32, per_client=48, max_batch=64, max_wait_us=3000, open_loop_s=5.0,
+              open_loads=(0.5, 0.75, 0.9)):
+    """BASELINE configs[4] (kokorox-openai/src/lib.rs:370-439): concurrent clients with mixed voices, incl. the mix
+    "af_sky.4+af_nicole.5" named into the device voice table, over one dispatcher in front of `models`.
+
+    Closed loop: `n_clients` clients, each sending its next request when the previous one is back (>= 1000 requests).
+    Open loop: Poisson arrivals at three offered loads (fractions of the closed-loop request rate), `open_loop_s` seconds
+    each; latency = completion - scheduled arrival, so queueing delay counts.  p50 / p99 / aggregate RTF per load."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from kokorox_amd import hip_koko as hk
+    rules = _serve_setup(models)
     d = hk.Dispatcher(models, max_batch=max_batch, max_wait_us=max_wait_us)
     rng = np.random.default_rng(0)
-    plan = [[(int(rng.integers(20, 129)), int(rng.integers(0, len(rules))), int(rng.integers(0, 3)), int(rng.integers(1, 2 ** 31)))
-             for _ in range(per_client)] for _ in range(n_clients)]
-    # untimed: one full-length request per model so that the arenas exist at the largest shape
-    for _ in models:
-        d.submit_ex(np.array([0] + [5] * 128 + [0], dtype=np.int64), voices=0, seed=1)
-    lat, audio, errs = [], [], []
+
+    def make_request(r):
+        k = int(r.integers(20, 129))
+        ids = np.concatenate([[0], r.integers(1, 178, size=k), [0]]).astype(np.int64)
+        return ids, rules[int(r.integers(0, len(rules)))], int(r.integers(0, 3)), int(r.integers(1, 2 ** 31))
+
+    # untimed: full-length requests on every model so that the arenas exist at the largest shape
+    warm = np.array([0] + [5] * 128 + [0], dtype=np.int64)
+    with ThreadPoolExecutor(max_workers=max(2 * len(models), 2)) as ex:
+        list(ex.map(lambda i: d.submit_ex(warm, voices=i % 3, seed=1 + i), range(4 * len(models))))
+    st0 = d.stats()
+    errs = []
+
+    # ---- closed loop ------------------------------------------------------------------------------------------------
+    lat, audio = [], []
     lock = threading.Lock()
 
     def client(c):
         r = np.random.default_rng(100 + c)
         try:
-            for (k, rule, fmt, seed) in plan[c]:
-                ids = np.concatenate([[0], r.integers(1, 178, size=k), [0]]).astype(np.int64)
+            for _ in range(per_client):
+                ids, voices, fmt, seed = make_request(r)
                 t = time.perf_counter()
-                w = d.submit_ex(ids, voices=rules[rule], seed=seed, fmt=fmt)
+                w = d.submit_ex(ids, voices=voices, seed=seed, fmt=fmt)
                 dt = time.perf_counter() - t
                 with lock:
                     lat.append(dt)
@@ -186,19 +225,65 @@ def serve_leg(models, n_clients=32, per_client=4, max_batch=64, max_wait_us=3000
     for t in th:
         t.join()
     wall = time.perf_counter() - t0
-    st = d.stats()
-    d.close()
+    st1 = d.stats()
     if errs or not lat:
+        d.close()
         return {"error": errs[:3]}
-    lat = np.sort(np.array(lat))
-    return {"clients": n_clients, "requests": int(len(lat)), "models": len(models), "wall_s": wall,
-            "audio_s": float(np.sum(audio)), "aggregate_rtf": float(np.sum(audio) / wall),
-            "latency_p50_ms": float(lat[len(lat) // 2] * 1e3), "latency_p99_ms": float(lat[int(len(lat) * 0.99)] * 1e3),
-            "requests_per_s": len(lat) / wall, "batches": st["batches"] - len(models), "max_batch": st["max_batch"],
-            "batches_per_model": st["batches_per_model"],
-            "workload": "20..128-phoneme requests, five voice rules (three single voices, af_sky.4+af_nicole.5, "
-                        "bf_emma.7+af_sky.3) through the device voice table, f32 mono / f32 stereo / PCM16 mixed, free-running "
-                        "durations, noise on"}
+    closed = _lat_summary(lat, audio, wall)
+    closed.update({"clients": n_clients, "batches": st1["batches"] - st0["batches"], "max_batch": st1["max_batch"],
+                   "batches_per_model": [b1 - b0 for b0, b1 in zip(st0["batches_per_model"], st1["batches_per_model"])]})
+    progress(f"serve closed loop: {closed['requests']} requests in {wall:.2f} s, {closed['aggregate_rtf']:.0f}x, "
+             f"p50/p99 {closed['latency_p50_ms']:.0f}/{closed['latency_p99_ms']:.0f} ms")
+
+    # ---- open loop: Poisson arrivals at fractions of the closed-loop rate ---------------------------------------------
+    open_runs = []
+    for load in open_loads:
+        rate = load * closed["requests_per_s"]
+        n_req = max(50, int(rate * open_loop_s))
+        r = np.random.default_rng(int(load * 1000))
+        arrivals = np.cumsum(r.exponential(1.0 / rate, size=n_req))
+        reqs = [make_request(r) for _ in range(n_req)]
+        lat_o, audio_o = [], []
+
+        def fire(i, t_start):
+            try:
+                ids, voices, fmt, seed = reqs[i]
+                w = d.submit_ex(ids, voices=voices, seed=seed, fmt=fmt)
+                done = time.perf_counter()
+                with lock:
+                    lat_o.append(done - (t_start + arrivals[i]))
+                    audio_o.append(w.shape[0] / 24000.0)
+            except Exception as e:  # pragma: no cover
+                errs.append(repr(e))
+
+        b0 = d.stats()
+        with ThreadPoolExecutor(max_workers=256) as ex:
+            t_start = time.perf_counter()
+            for i in range(n_req):
+                dt = t_start + arrivals[i] - time.perf_counter()
+                if dt > 0:
+                    time.sleep(dt)
+                ex.submit(fire, i, t_start)
+        w_o = time.perf_counter() - t_start
+        b1 = d.stats()
+        if errs or not lat_o:
+            break
+        run = _lat_summary(lat_o, audio_o, w_o)
+        run.update({"offered_load": load, "offered_requests_per_s": rate, "batches": b1["batches"] - b0["batches"],
+                    "mean_batch": (b1["requests"] - b0["requests"]) / max(1, b1["batches"] - b0["batches"])})
+        open_runs.append(run)
+        progress(f"serve open loop {load:.2f}: {run['requests']} requests, p50/p99 {run['latency_p50_ms']:.0f}/"
+                 f"{run['latency_p99_ms']:.0f} ms, {run['aggregate_rtf']:.0f}x")
+    d.close()
+    if errs:
+        return {"error": errs[:3]}
+    out = dict(closed)  # (the closed-loop figures stay at the top level: the keys earlier rounds reported)
+    out.update({"models": len(models), "open_loop": open_runs,
+                "workload": "20..128-phoneme requests, five voice rules (three single voices, af_sky.4+af_nicole.5, "
+                            "bf_emma.7+af_sky.3) through the device voice table, f32 mono / f32 stereo / PCM16 mixed, free-running "
+                            "durations, noise on; closed loop = each client waits for its answer; open loop = Poisson arrivals at "
+                            "the stated fraction of the closed-loop request rate, latency from the scheduled arrival"})
+    return out
 
 
 def replicas_main(a):
@@ -261,25 +346,28 @@ def replicas_main(a):
     th = [threading.Thread(target=worker, args=(r,)) for r in range(N)]
     for t in th:
         t.start()
-    bar.wait()
-    t0 = time.perf_counter()
-    bar.wait()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+    wall = 0.0
+    try:
+        bar.wait()
+        t0 = time.perf_counter()
+        bar.wait()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    except threading.BrokenBarrierError:  # a worker failed and aborted the barrier: report ITS error below
+        pass
     for t in th:
         t.join()
-    if errs:
-        raise SystemExit(f"replica failed: {errs[0]}")
+    if errs or wall <= 0.0:
+        raise SystemExit(f"replica failed: {errs[0] if errs else 'barrier broken'}")
     for (m, ids, styles, audio, frames) in state:
         assert (frames.cpu().numpy() == F).all()
     finite = all(bool(torch.isfinite(s[3][:, : 600 * F]).all().item()) for s in state)
     audio_s_per_step = N * B * F * 600 / 24000.0
-    f16x3 = models[0].get_conv_mode() == 1
     out = {
         "metric": f"real-time factor (audio-s/wall-s), 24 kHz, batch={B}",
         "value": audio_s_per_step * a.steps / wall, "unit": "x realtime", "n_gpus": N, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (f16x3 split MFMA: 3 f16 MFMAs per product on hi/lo halves, f32 accumulate)" if f16x3 else "f32",
+        "dtype": dtype_label(models[0].get_conv_mode()),
         "data": "synthetic (seeded random-init Kokoro-82M weights, uniform phoneme ids, N(0,0.1) voice rows)",
         "config": {"workload": f"batch={B}/GPU synthetic {a.phonemes}-phoneme utterances (T={T}), durations pinned "
                                f"3,3,3,4 -> F={F} frames = {F * 600 / 24000.0:.2f} s each, noise on, inputs in HBM",
@@ -309,6 +397,8 @@ def main():
     ap.add_argument("--reduced", type=int, default=1,
                     help="also time the opt-in reduced-precision mode (one f16 MFMA per product) as a secondary block (N=1)")
     ap.add_argument("--serve", type=int, default=1, help="also run the 32-client serving leg (configs[4]) on rank 0 at N=1")
+    ap.add_argument("--serve-models", type=int, default=2, help="models per GPU behind the serving leg's dispatcher")
+    ap.add_argument("--latency-b1", type=int, default=50, help="batch-1 calls timed for the latency_b1 block (configs[1]; 0 = skip)")
     ap.add_argument("--replicas", type=int, default=0,
                     help="single-process form: N models from kx_create_replicas, one host thread each (instead of torchrun)")
     a = ap.parse_args()
@@ -396,7 +486,8 @@ def main():
     progress(f"{a.steps} timed steps: {wall:.3f} s")
     n_launch, conv_ms, conv_flops = model.profile_read()
     stats_launches, stats_bytes = model.profile_aux()
-    f16x3 = model.get_conv_mode() == 1
+    conv_mode = model.get_conv_mode()
+    f16x3 = conv_mode in (1, 4)  # both run the f16 matrix pipe (mode 4 = the opt-in reduced precision, labelled as such)
     det = model.profile_detail()
     conv_bytes = float(det[:, 9].sum()) if len(det) else 0.0
     if a.detail and rank == 0:
@@ -439,15 +530,22 @@ def main():
         model.infer_device(ids.data_ptr(), T, lens, styles.data_ptr(), speeds, buf.data_ptr(), cap,
                            frames.data_ptr(), seed=2)
         fence()
+        n_free = max(5, a.steps // 2)
         t1 = time.perf_counter()
-        model.infer_device(ids.data_ptr(), T, lens, styles.data_ptr(), speeds, buf.data_ptr(), cap,
-                           frames.data_ptr(), seed=2)
+        for _ in range(n_free):
+            model.infer_device(ids.data_ptr(), T, lens, styles.data_ptr(), speeds, buf.data_ptr(), cap,
+                               frames.data_ptr(), seed=2)
         fence()
-        w1 = time.perf_counter() - t1
-        sf = int(frames.cpu().numpy().sum())
-        progress(f"free-running step: {w1:.3f} s, sum frames {sf}")
-        free = {"sum_frames_rank0": sf, "audio_s_rank0": sf * 600 / 24000.0, "wall_s": w1,
-                "rtf_rank0": sf * 600 / 24000.0 / w1}
+        w1 = (time.perf_counter() - t1) / n_free
+        fr_free = frames.cpu().numpy()
+        sf = int(fr_free.sum())
+        progress(f"free-running steps: {w1:.3f} s each, sum frames {sf}")
+        pinned_us_per_frame = wall / a.steps / (B * F) * 1e6
+        free = {"steps": n_free, "sum_frames_rank0": sf, "min_frames": int(fr_free.min()), "max_frames": int(fr_free.max()),
+                "audio_s_rank0": sf * 600 / 24000.0, "wall_s": w1, "rtf_rank0": sf * 600 / 24000.0 / w1,
+                # ragged batch against the pinned (equal-length) one, per frame of audio
+                "us_per_frame": w1 / sf * 1e6, "pinned_us_per_frame": pinned_us_per_frame,
+                "per_frame_vs_pinned": (w1 / sf * 1e6) / pinned_us_per_frame}
         del buf
 
     # ---- the same batch through the host-buffer boundary (kx_infer: H2D of ids/styles, forward, D2H of the audio) ----
@@ -485,7 +583,7 @@ def main():
     # ---- secondary: the opt-in reduced-precision mode (BASELINE configs[2] says "bf16"; the reference's model_fp16 /
     # quantised variants, hf_cache.rs:135-144).  Never `value`: narrower than the reference's fp32 default. ----
     reduced = None
-    if a.reduced and rank == 0 and world == 1 and f16x3:
+    if a.reduced and rank == 0 and world == 1 and conv_mode == 1:
         model.set_pinned_durations([3, 3, 3, 4])
         model.set_utterance_base(rank * B)
         model.set_conv_mode(4)
@@ -500,8 +598,8 @@ def main():
             w3 = time.perf_counter() - t3
             n3, ms3, fl3 = model.profile_read()
             model.profile_enable(False)
-            det3 = model.profile_detail()
-            # the launches that actually ran one MFMA per product: the stride-1 128-row convs of decoder and generator
+            # (the family mixes launches at one MFMA per product -- the decoder / generator direct-A convs -- with launches
+            # at three: `achieved` is algorithmic FLOPs over time, the issue factor is stated, no pipe utilisation is derived)
             ach3 = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
             reduced = {"mode": "KOKOROX_CONV=f16: one v_mfma_f32_32x32x16_f16 per product in the decoder / generator convs of the "
                                "direct-A kernel (f16 operands, f32 accumulate); duration head, F0/N predictor, source, STFT f32-class",
@@ -514,6 +612,31 @@ def main():
             progress(f"reduced-precision steps: {w3:.3f} s")
         finally:
             model.set_conv_mode(1)
+
+    # ---- BASELINE configs[1]: one 128-phoneme utterance, fp32-class default mode, batch 1: latency of a call ----------
+    lat_b1 = None
+    if a.latency_b1 and rank == 0 and world == 1:
+        model.set_pinned_durations([3, 3, 3, 4])
+        model.set_utterance_base(rank * B)
+        ids1, st1, lens1 = ids[:1].contiguous(), styles[:1].contiguous(), lens[:1].copy()
+        a1 = torch.empty((1, audio_ld), dtype=torch.float32, device=dev)
+        f1 = torch.zeros(1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+
+        def one():
+            t = time.perf_counter()
+            model.infer_device(ids1.data_ptr(), T, lens1, st1.data_ptr(), speeds, a1.data_ptr(), audio_ld, f1.data_ptr(), seed=2)
+            model.sync()
+            return time.perf_counter() - t
+
+        for _ in range(5):
+            one()
+        ts = np.sort(np.array([one() for _ in range(a.latency_b1)]))
+        lat_b1 = {"calls": int(len(ts)), "median_ms": float(ts[len(ts) // 2] * 1e3), "p99_ms": float(ts[min(len(ts) - 1, int(len(ts) * 0.99))] * 1e3),
+                  "min_ms": float(ts[0] * 1e3), "rtf_at_median": F * 600 / 24000.0 / float(ts[len(ts) // 2]),
+                  "workload": f"batch 1, one {a.phonemes}-phoneme utterance (T={T}), durations pinned 3,3,3,4 -> F={F} "
+                              f"({F * 600 / 24000.0:.2f} s of audio), inputs in HBM, kx_infer_device + kx_sync per call"}
+        progress(f"batch-1 latency: median {lat_b1['median_ms']:.2f} ms, p99 {lat_b1['p99_ms']:.2f} ms")
 
     if rank == 0:
         flops_per_utt = (0.1635 * T + 1.317 * F) * 1e9  # SURVEY.md §8d model
@@ -528,7 +651,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (f16x3 split MFMA: 3 f16 MFMAs per product on hi/lo halves, f32 accumulate)" if f16x3 else "f32",
+            "dtype": dtype_label(conv_mode),
             "data": "synthetic (seeded random-init Kokoro-82M weights, uniform phoneme ids, N(0,0.1) voice rows)",
             "config": {
                 "workload": f"batch={B}/GPU synthetic {a.phonemes}-phoneme utterances (T={T}), durations pinned "
@@ -546,10 +669,20 @@ def main():
             # count tools/summarize_pmc.py checks FETCH_SIZE against)
             "in_stats": {"launches_per_step": stats_launches / max(a.steps, 1), "bytes_per_step": stats_bytes / max(a.steps, 1)},
             "free_running": free,
+            "latency_b1": lat_b1,
             "pcie_inclusive": pcie,
             "reduced_precision": reduced,
         }
-        out["serve"] = serve_leg([model]) if (world == 1 and a.serve) else None
+        out["serve"] = None
+        if world == 1 and a.serve:
+            # two models on the GPU: while one batch is in its host-side phases (copies, the mid-forward sync, packing) or
+            # in its recurrences, the other model's batch keeps the chip busy (two in-flight batches per GPU)
+            serve_models = [model] + [hk.HipKoko.new(blob_path, device=dev_index) for _ in range(max(0, a.serve_models - 1))]
+            try:
+                out["serve"] = serve_leg(serve_models)
+            finally:
+                for m2 in serve_models[1:]:
+                    m2.close()
         if world == 1 and a.cpu_utts > 0:
             out["cpu_baseline"] = cpu_baseline(blob_path, a.cpu_utts, a.phonemes, pinned)
         else:

@@ -959,7 +959,8 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     // idle: 14.1 -> 11.9 ms), 14 % at batch 4, 6 % at batch 16; at batch 64 every launch fills the chip and they change
     // nothing (125.1 vs 125.1 ms) while the per-launch event timings of the profile mode would overlap.  So: lanes for
     // small batches only.
-    n_lanes_ = lanes_cfg_ ? lanes_cfg_ : (B <= 32 ? N_LANES : 1);
+    // (with the per-launch event timing on, one lane: intervals recorded on overlapping streams would be summed side by side)
+    n_lanes_ = prof_on_ ? 1 : (lanes_cfg_ ? lanes_cfg_ : (B <= 32 ? N_LANES : 1));
     hT_.assign(lens_host, lens_host + B);
     hF_.assign(B, 0);
     const int Tp = up4(Tmax);

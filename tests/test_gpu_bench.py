@@ -49,12 +49,20 @@ def test_bench_blocks_and_single_process_replicas():
     "bf16") and the single-process form of the N-GPU run (`--replicas`, kx_create_replicas + one host thread per model),
     rehearsed with two replicas on the one GPU."""
     r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--batch", "4", "--cpu-utts", "0",
-                        "--free-run", "0", "--pcie", "0"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                        "--pcie", "0"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
+    fr = d["free_running"]
+    assert fr["steps"] >= 5 and fr["min_frames"] <= fr["max_frames"] and fr["per_frame_vs_pinned"] > 0
     s = d["serve"]
-    assert s["clients"] == 32 and s["requests"] == 128 and s["aggregate_rtf"] > 0 and s["latency_p99_ms"] >= s["latency_p50_ms"] > 0
-    assert s["batches"] < s["requests"] and s["max_batch"] > 1
+    assert s["clients"] == 32 and s["requests"] >= 1000 and s["aggregate_rtf"] > 0 and s["latency_p99_ms"] >= s["latency_p50_ms"] > 0
+    assert s["batches"] < s["requests"] and s["max_batch"] > 1 and s["wall_s"] > 1.0 and s["models"] == 2
+    assert all(b > 0 for b in s["batches_per_model"])
+    assert [o["offered_load"] for o in s["open_loop"]] == [0.5, 0.75, 0.9]
+    for o in s["open_loop"]:
+        assert o["requests"] >= 50 and o["latency_p99_ms"] >= o["latency_p50_ms"] > 0 and o["aggregate_rtf"] > 0
+    lb = d["latency_b1"]
+    assert lb["calls"] == 50 and 0 < lb["min_ms"] <= lb["median_ms"] <= lb["p99_ms"]
     rp = d["reduced_precision"]
     assert rp["value"] > 0 and rp["roofline"]["frac"] > 0 and "f16" in rp["mode"]
     assert "traffic_source" in d["roofline"]

@@ -17,7 +17,8 @@ from kokorox_amd import weights as W  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--clients", type=int, default=32)
-    ap.add_argument("--requests", type=int, default=4, help="per client")
+    ap.add_argument("--requests", type=int, default=48, help="per client (closed loop)")
+    ap.add_argument("--open-loop-s", type=float, default=5.0, help="seconds per open-loop load (0 = closed loop only)")
     ap.add_argument("--max-batch", type=int, default=64)
     ap.add_argument("--max-wait-us", type=int, default=3000)
     ap.add_argument("--models", default="0", help="device ids, one model each (e.g. 0,0 = two models on one GPU)")
@@ -27,7 +28,8 @@ def main():
     blob = W.ensure_synthetic_blob()
     models = hk.HipKoko.replicas(blob, ids) if len(ids) > 1 else [hk.HipKoko.new(blob, device=ids[0])]
     out = bench.serve_leg(models, n_clients=a.clients, per_client=a.requests, max_batch=1 if a.serial else a.max_batch,
-                          max_wait_us=0 if a.serial else a.max_wait_us)
+                          max_wait_us=0 if a.serial else a.max_wait_us, open_loop_s=a.open_loop_s,
+                          open_loads=(0.5, 0.75, 0.9) if a.open_loop_s > 0 else ())
     out["serial"] = bool(a.serial)
     print(json.dumps(out))
     for m in models:
