@@ -397,6 +397,9 @@ def main():
     ap.add_argument("--reduced", type=int, default=1,
                     help="also time the opt-in reduced-precision mode (one f16 MFMA per product) as a secondary block (N=1)")
     ap.add_argument("--serve", type=int, default=1, help="also run the 32-client serving leg (configs[4]) on rank 0 at N=1")
+    ap.add_argument("--durations", default="pinned", choices=["pinned", "free"],
+                    help="free = the timed steps run on the predicted (ragged) durations: a profiling mode (rocprof of the "
+                         "ragged step, tools/ragged_profile.sh); the headline is the pinned workload")
     ap.add_argument("--serve-models", type=int, default=2, help="models per GPU behind the serving leg's dispatcher")
     ap.add_argument("--latency-b1", type=int, default=50, help="batch-1 calls timed for the latency_b1 block (configs[1]; 0 = skip)")
     ap.add_argument("--replicas", type=int, default=0,
@@ -459,6 +462,14 @@ def main():
     torch.cuda.synchronize()
     model.set_utterance_base(rank * B)
     model.set_pinned_durations([3, 3, 3, 4])
+    free_main = a.durations == "free"
+    if free_main:  # profiling mode: ragged batch in the timed region
+        model.set_pinned_durations(None)
+        need = model.infer_device(ids.data_ptr(), T, lens, styles.data_ptr(), speeds, audio.data_ptr(), audio_ld, frames.data_ptr(), seed=2)
+        if need > audio_ld:
+            audio_ld = int(need)
+            audio = torch.empty((B, audio_ld), dtype=torch.float32, device=dev)
+        a.free_run = a.pcie = a.reduced = a.serve = a.latency_b1 = 0
 
     def step():
         need = model.infer_device(ids.data_ptr(), T, lens, styles.data_ptr(), speeds, audio.data_ptr(), audio_ld,
@@ -509,10 +520,14 @@ def main():
     wall = float(wall_t.item())
 
     fr = frames.cpu().numpy()
-    assert (fr == F).all(), fr
-    a_host = audio[:, : 600 * F].float()
-    finite = bool(torch.isfinite(a_host).all().item())
-    audio_s_per_step = world * B * F * 600 / 24000.0
+    if free_main:
+        finite = all(bool(torch.isfinite(audio[b, : 600 * int(fr[b])]).all().item()) for b in range(B))
+        audio_s_per_step = world * float(fr.sum()) * 600 / 24000.0  # (rank 0's frames stand for every rank's)
+    else:
+        assert (fr == F).all(), fr
+        a_host = audio[:, : 600 * F].float()
+        finite = bool(torch.isfinite(a_host).all().item())
+        audio_s_per_step = world * B * F * 600 / 24000.0
     rtf = audio_s_per_step * a.steps / wall
     utt_s = world * B * a.steps / wall
 
@@ -654,9 +669,11 @@ def main():
             "dtype": dtype_label(conv_mode),
             "data": "synthetic (seeded random-init Kokoro-82M weights, uniform phoneme ids, N(0,0.1) voice rows)",
             "config": {
-                "workload": f"batch={B}/GPU synthetic {a.phonemes}-phoneme utterances (T={T}), durations pinned "
-                            f"3,3,3,4 -> F={F} frames = {F * 600 / 24000.0:.2f} s each, noise on, inputs in HBM",
-                "batch_per_gpu": B, "tokens": T, "frames": F, "parallelism": f"utterance-sharded x{world}, "
+                "workload": (f"batch={B}/GPU synthetic {a.phonemes}-phoneme utterances (T={T}), durations pinned "
+                             f"3,3,3,4 -> F={F} frames = {F * 600 / 24000.0:.2f} s each, noise on, inputs in HBM") if not free_main else
+                            (f"PROFILING MODE --durations free: batch={B}/GPU synthetic {a.phonemes}-phoneme utterances, PREDICTED "
+                             f"durations (ragged: {int(fr.min())}..{int(fr.max())} frames, sum {int(fr.sum())}), noise on, inputs in HBM"),
+                "batch_per_gpu": B, "tokens": T, "frames": F if not free_main else int(fr.sum()) / B, "parallelism": f"utterance-sharded x{world}, "
                 "one-time weight broadcast",
             },
             "utterances_per_s": utt_s,
