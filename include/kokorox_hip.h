@@ -286,8 +286,9 @@ int kx_test_conv1d_epilogue(int device_id, const float* x, int B, int Cin, int L
 /* Both at once, as the generator's resblock convs run: fused AdaIN affine + activation on the input AND the epilogue forms
  * (residual / running sum / scale / fused statistics), on a RAGGED batch when lens [B] is given (utterance b is lens[b]
  * columns long: columns past its output length stay as they were, its statistics cover its own columns only) and, with
- * pad_ld != 0, on rows padded to a multiple of 32 floats as the model lays them out (input and residual padding is NaN,
- * the output padding holds a sentinel that must survive).  Stride 1, not transposed. */
+ * pad_ld & 1, on rows padded to a multiple of 32 floats as the model lays them out (input and residual padding is NaN,
+ * the output padding holds a sentinel that must survive); pad_ld & 2 = the flat list of live tiles the model hands the
+ * direct-A kernels on a batch of more than one utterance instead of a (longest length) x B grid.  Stride 1, not transposed. */
 int kx_test_conv1d_full(int device_id, const float* x, int B, int Cin, int L, const int32_t* lens, int pad_ld,
                         const float* w, const float* bias, int Cout, int k, int pad, int dil, int act, float slope,
                         const float* alpha, const float* norm, const float* resid, int accumulate, float out_mul,

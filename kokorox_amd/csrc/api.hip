@@ -374,6 +374,7 @@ struct ConvTestExtra {  // epilogue forms beyond bias: residual, accumulate into
     float* stats_out = nullptr;  // [B][Cout][2] = sum, sum of squares over the stored row
     const int32_t* lens = nullptr;  // [B] valid input columns per utterance (ragged batch); null = all L
     int pad_ld = 0;              // rows padded to a multiple of 32 floats as in the model (x padding = NaN, y padding checked)
+    int flat = 0;                // ragged batches: the flat tile list the model gives the direct-A kernels (ConvArgs::tile_prefix)
 };
 }  // namespace
 
@@ -519,7 +520,26 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
             a.w_unscale = std::ldexp(1.0f, -ws);
             a.x_prescale = 1.0f;
             a.xcd_swizzle = 1;
-            kx::launch_conv1d_f16x3(a, BM, B, transposed ? L + 1 : Lout, nullptr);
+            const int max_cols = transposed ? L + 1 : Lout;
+            if (ex.flat && B > 1) {
+                const int fbn = kx::conv16_flat_bn(a, BM, B, max_cols);
+                if (fbn) {
+                    const kx::LenMap lm = transposed ? a.in_len : a.out_len;
+                    int* d_pre = dm.get<int>((size_t)B + 1);
+                    kx::launch_tile_prefix(lm, transposed ? 1 : 0, fbn, B, d_pre, nullptr);
+                    int total = 0;
+                    for (int b = 0; b < B; ++b) {
+                        const int cols = lens[b] * lm.mul + lm.add + (transposed ? 1 : 0);
+                        total += cols > 0 ? (cols + fbn - 1) / fbn : 0;
+                    }
+                    a.tile_prefix = d_pre;
+                    a.flat_ny = (rows + 127) / 128;
+                    a.flat_B = B;
+                    a.flat_tiles_host = total;
+                    a.flat_bn_host = fbn;
+                }
+            }
+            kx::launch_conv1d_f16x3(a, BM, B, max_cols, nullptr);
         } else {
             kx::launch_conv1d(a, BM, B, transposed ? L + 1 : Lout, nullptr);
         }
@@ -583,7 +603,8 @@ int kx_test_conv1d_full(int device_id, const float* x, int B, int Cin, int L, co
     ex.out_div = out_div;
     ex.stats_out = stats_out;
     ex.lens = lens;
-    ex.pad_ld = pad_ld;
+    ex.pad_ld = pad_ld & 1;
+    ex.flat = (pad_ld >> 1) & 1;
     const int Lout = L + 2 * pad - dil * (k - 1);
     return test_conv1d_impl(device_id, x, B, Cin, L, w, bias, Cout, k, 1, pad, dil, 0, act, slope, alpha, norm, y, Lout, mode, ex,
                             err, err_len);

@@ -474,6 +474,21 @@ void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int
     }
 }
 
+// The tile width of the launch below when it goes to a kernel that can take a flat tile list (the direct-A conv family), else
+// 0.  Must mirror launch_conv1d_f16x3's dispatch exactly (launch_da_inst checks the width the host assumed).
+int conv16_flat_bn(const ConvArgs& a, int BM, int B, int max_cols) {
+    static const int on = env_int("KX_FLAT", 1);
+    if (!on || BM != 128 || B < 2 || max_cols <= 0 || a.merge_T > 0 || a.ws_force == 1 || a.stamps) return 0;
+    if (a.K == 1 && a.stride == 1 && !a.stat_part && !a.in_up2 && a.n_chunks16 >= 3 && a.act != ACT_SNAKE) return 0;  // k = 1 GEMM forms
+    int bn, wn;
+    conv16_pick_tile(BM, max_cols, B, a.Cout, a.K, a.dil, a.stride, &bn, &wn, a.ws_force, a.stat_part != nullptr, a.act, a.n_chunks16,
+                     a.prec1 != 0);
+    if (conv16_da_s16_shape(BM, a.K, a.dil, a.stride, a.act, a.n_chunks16, a.merge_T > 0, a.prec1 != 0)) return bn;  // 192 / 128
+    if (bn == 128 && wn == 1) return conv16_use_da(BM, a.K, a.dil, a.stride, a.merge_T > 0) ? 128 : 0;
+    if (bn == 128) return 0;
+    return conv16_use_da(BM, a.K, a.dil, a.stride, a.merge_T > 0) ? 256 : 0;
+}
+
 void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStream_t s) {
 #ifdef KX_ONLY_MAIN  // (compile-time probe builds: just the dominant instantiation, ~10 s instead of ~3 min)
     launch_inst16_pf<128, 256, 2, 2, ACT_SNAKE, 3, true>(a, B, max_cols, s);

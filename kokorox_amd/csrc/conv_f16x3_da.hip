@@ -97,14 +97,33 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z;
     // XCD-aware tile order (as conv1d_f16x3_kernel: workgroups are dealt round-robin over the 8 XCDs by linear block id, and
     // the blocks of one XCD get a contiguous range of tiles so that the window overlap of neighbouring column tiles is an L2
     // hit), extended to the row tiles: the tiles of one utterance are ordered (column tile, row tile) with the ROW tile
     // fastest, so the two row tiles of a 256-channel layer, which stage the same input window, run side by side on one XCD
     // and the second one's input comes from L2 instead of HBM.
-    int tile_x = blockIdx.x, ct = blockIdx.y;
-    {
+    int tile_x = blockIdx.x, ct = blockIdx.y, b = blockIdx.z;
+    if (a.tile_prefix) {
+        // flat list of a ragged batch: every workgroup is a live tile, and the XCD ranges run over the whole list (in the dense
+        // grid every XCD gets the same eighth of every utterance's slab: the ones that hold the tails of shorter utterances
+        // run empty and the launch costs as much as B utterances of the longest length)
+        const int N = gridDim.x, l = blockIdx.x, ny = a.flat_ny;
+        int lp = l;
+        if (a.xcd_swizzle && N >= 16) {
+            const int cls = l & 7, q = N >> 3, rem = N & 7;  // class c holds q + (c < rem) blocks
+            lp = cls * q + (cls < rem ? cls : rem) + (l >> 3);
+        }
+        const int gt = lp / ny;  // global column tile
+        ct = lp - gt * ny;
+        int lo = 0, hi = a.flat_B;  // the utterance with tile_prefix[b] <= gt < tile_prefix[b + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.tile_prefix[mid] <= gt) lo = mid;
+            else hi = mid;
+        }
+        b = __builtin_amdgcn_readfirstlane(lo);
+        tile_x = gt - a.tile_prefix[b];
+    } else {
         const int nx = gridDim.x, ny = gridDim.y, N = nx * ny;
         const int l = blockIdx.x + nx * blockIdx.y;  // linear id inside the utterance's slab (dispatch order)
         int lp = l;
@@ -1074,6 +1093,12 @@ static void launch_da_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s
     constexpr size_t lds = lds_x > lds_scr ? lds_x : lds_scr;
     dim3 grid((max_cols + BN - 1) / BN, (a.Cout + 127) / 128, B);
     KX_REQUIRE(grid.x > 0 && grid.y > 0 && grid.y < 65536 && B > 0 && B < 65536, "conv1d f16x3 da: bad grid");
+    if (a.tile_prefix) {  // flat tile list: the host counted the live column tiles for THIS tile width (a.flat_tiles_host)
+        KX_REQUIRE(a.flat_ny == (int)grid.y && a.flat_B == B && a.flat_bn_host == BN && a.flat_tiles_host > 0 &&
+                       (long)a.flat_tiles_host * grid.y < (1L << 30),
+                   "conv1d f16x3 da: flat tile list does not match the launch");
+        grid = dim3((unsigned)a.flat_tiles_host * grid.y, 1, 1);
+    }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     KX_HIP(hipGetLastError());
 }

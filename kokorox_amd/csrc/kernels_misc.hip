@@ -277,6 +277,23 @@ __global__ __launch_bounds__(256) void style_fc_kernel(const FcDesc* desc, const
         out[b * out_bs + d.out_off + o] = acc + d.b[o];
     }
 }
+// ---- flat tile list of a ragged batch (ConvArgs::tile_prefix) ----------------------------------------------------
+__global__ void tile_prefix_kernel(LenMap len, int extra, int bn, int B, int* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int acc = 0;
+    for (int b = 0; b < B; ++b) {
+        out[b] = acc;
+        const int cols = len.lens[b] * len.mul + len.add + extra;
+        acc += cols > 0 ? (cols + bn - 1) / bn : 0;
+    }
+    out[B] = acc;
+}
+
+void launch_tile_prefix(LenMap len, int extra, int bn, int B, int* out, hipStream_t s) {
+    hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(64), 0, s, len, extra, bn, B, out);
+    KX_HIP(hipGetLastError());
+}
+
 void launch_style_fc(const FcDesc* d_desc, int n_desc, const float* styles, float* out, long out_bs, int B,
                      hipStream_t s) {
     hipLaunchKernelGGL(style_fc_kernel, dim3(n_desc, B), dim3(256), 0, s, d_desc, styles, out, out_bs);

@@ -119,7 +119,23 @@ struct ConvArgs {
     int prec1;  // direct-A conv: the reduced-precision form (one f16 MFMA per product; KOKOROX_CONV=f16, opt-in)
     int dephase_cycles, dephase_mode;  // direct-A conv: start delay of half of the first round of workgroups (0 = off)
     int dbg;  // timing ablations (env KX_DBG): 1 skip input staging, 2 skip weight copies, 4 skip MFMA, 8 skip epilogue
+    // Flat tile list of a ragged batch (direct-A kernels): tile_prefix[b] = column tiles of the utterances before b (so
+    // tile_prefix[B] = all of them); the grid is then ONE dimension of tile_prefix[B] * flat_ny workgroups, none of them
+    // dead, and the XCD-aware order runs over the whole list.  null = the (max_cols / BN) x row tiles x B grid with
+    // early-exit workgroups.  (The dense grid deals each XCD the same eighth of EVERY utterance's slab, so on a ragged
+    // batch the XCDs that hold the slabs' tails run empty and the launch takes as long as if every utterance had the
+    // longest length: profiles/r04_ragged_attribution.txt.)
+    const int* tile_prefix;
+    int flat_ny;     // row tiles (the fastest index of the list)
+    int flat_B;
+    int flat_tiles_host, flat_bn_host;  // host side only: tile_prefix[B] as the host counted it, and the tile width it assumed
 };
+
+// tile_prefix of a LenMap for `bn`-column tiles (+ `extra` columns per utterance: the polyphase convs' L + 1), on the device
+void launch_tile_prefix(LenMap len, int extra, int bn, int B, int* out, hipStream_t s);
+// the launch geometry launch_conv1d_f16x3 will choose for these arguments if it can take a flat tile list: the tile width
+// (128 / 192 / 256 columns), or 0 when the launch goes to a kernel without the flat form
+int conv16_flat_bn(const ConvArgs& a, int BM, int B, int max_cols);
 
 struct ConvShape {
     int BM;  // 128, 64 or 32

@@ -245,6 +245,13 @@ class Model {
     bool dry_ = false;  // sizing pass: allocate (count) but launch nothing
     std::map<std::string, Tap> taps_;
 
+    // flat tile lists of the running call (ConvArgs::tile_prefix), one per (length map, tile width, stream)
+    struct PrefixKey { const int* lens; int mul, add, bn; hipStream_t stream; const int* dev; };
+    std::vector<PrefixKey> prefix_keys_;
+    int* d_prefix_ = nullptr;
+    size_t prefix_cap_ = 0, prefix_used_ = 0;
+    const int* tile_prefix_for(const LenMap& lm, int extra, int bn, int* total);
+
     struct PartInfo { const float2* part; int tiles, cols_per_tile, C; };
     std::map<const float*, PartInfo> parts_;  // output tensor -> fused statistics partials of its producer
 

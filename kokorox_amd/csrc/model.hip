@@ -575,6 +575,21 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
         a.merge_B = B_;
         max_cols = B_ * in.Lmax;
     }
+    // ragged batch: the direct-A kernels take a flat list of the live tiles instead of a (longest length) x B grid
+    if (f16 && B_ > 1) {
+        const int fbn = conv16_flat_bn(a, w.BM, B_, max_cols);
+        if (fbn) {
+            const LenMap& lm = (o.store == ST_UPSCATTER) ? a.in_len : a.out_len;
+            const int extra = o.store == ST_UPSCATTER ? 1 : 0;
+            int total = 0;
+            a.tile_prefix = tile_prefix_for(lm, extra, fbn, &total);
+            a.flat_ny = (w.rows + 127) / 128;
+            a.flat_B = B_;
+            a.flat_tiles_host = total;
+            a.flat_bn_host = fbn;
+            if (total <= 0) return;  // (nothing to compute)
+        }
+    }
     // diagnostic: KX_STAMP=<file> dumps per-workgroup timestamps of the first 128->128 k=11 launch
     static const char* stamp_path = getenv("KX_STAMP");
     static bool stamped = false;
@@ -638,6 +653,38 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
             fclose(f);
         }
     }
+}
+
+// The device prefix table of (length map, extra columns, tile width) for the running call: built once per call and key by a
+// one-thread kernel on the current stream, from the same device lengths the kernels read; *total = its last entry, counted
+// on the host from the host copies of those lengths (the grid size).
+const int* Model::tile_prefix_for(const LenMap& lm, int extra, int bn, int* total) {
+    const std::vector<int>& hl = (lm.lens == dT_) ? hT_ : hF_;
+    KX_REQUIRE(lm.lens == dT_ || lm.lens == dF_, "internal: tile prefix of an unknown length array");
+    int tot = 0;
+    for (int b = 0; b < B_; ++b) {
+        const int cols = hl[b] * lm.mul + lm.add + extra;
+        tot += cols > 0 ? (cols + bn - 1) / bn : 0;
+    }
+    *total = tot;
+    for (const PrefixKey& k : prefix_keys_)
+        if (k.lens == lm.lens && k.mul == lm.mul && k.add == lm.add + extra && k.bn == bn && k.stream == stream_) return k.dev;
+    const size_t need = (size_t)(B_ + 1);
+    if (prefix_used_ + need > prefix_cap_) {  // (grown like the arenas; tables of this call that are in use stay where they are)
+        const size_t want = std::max<size_t>(prefix_cap_ * 2, (size_t)64 * need);
+        int* p = nullptr;
+        KX_HIP(hipMalloc((void**)&p, want * sizeof(int)));
+        owned_.push_back(p);  // (the old block stays alive until the model goes: launches of this call may still read it)
+        d_prefix_ = p;
+        prefix_cap_ = want;
+        prefix_used_ = 0;
+    }
+    int* dev = d_prefix_ + prefix_used_;
+    prefix_used_ += need;
+    launch_tile_prefix(lm, extra, bn, B_, dev, stream_);
+    // (keyed by stream too: a table built on one lane's stream is ordered before that lane's launches only)
+    prefix_keys_.push_back(PrefixKey{lm.lens, lm.mul, lm.add + extra, bn, stream_, dev});
+    return dev;
 }
 
 void Model::stats(const T& x, const std::string& fc_key) {
@@ -955,6 +1002,8 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     parts_.clear();
     p1_region_ = false;
     lane_ev_used_ = 0;
+    prefix_keys_.clear();  // the flat tile lists belong to one call's lengths
+    prefix_used_ = 0;
     // Measured (profiles/r03_lanes_dephase.txt): side-by-side chains take 15 % off the batch-1 step (small grids leave CUs
     // idle: 14.1 -> 11.9 ms), 14 % at batch 4, 6 % at batch 16; at batch 64 every launch fills the chip and they change
     // nothing (125.1 vs 125.1 ms) while the per-launch event timings of the profile mode would overlap.  So: lanes for

@@ -548,9 +548,10 @@ def conv1d_epilogue(x, w, bias=None, pad=0, dil=1, resid=None, y_init=None, out_
 
 
 def conv1d_full(x, w, bias=None, pad=0, dil=1, act=0, slope=0.0, alpha=None, norm=None, resid=None, y_init=None,
-                out_mul=1.0, out_div=1.0, want_stats=False, lens=None, pad_ld=False, mode=1, device=0):
+                out_mul=1.0, out_div=1.0, want_stats=False, lens=None, pad_ld=False, flat=False, mode=1, device=0):
     """Stride-1 conv with the fused input transform (AdaIN affine + leaky / snake) AND the epilogue forms, on a ragged
-    batch (lens[b] valid input columns) and, with pad_ld, on the model's padded rows.  Returns y or (y, stats[B,Cout,2])."""
+    batch (lens[b] valid input columns), with pad_ld on the model's padded rows, with flat through the flat list of live
+    tiles the model gives the direct-A kernels.  Returns y or (y, stats[B,Cout,2])."""
     lib = load_library()
     x, w = _f32(x), _f32(w)
     B, Cin, L = x.shape
@@ -559,7 +560,7 @@ def conv1d_full(x, w, bias=None, pad=0, dil=1, act=0, slope=0.0, alpha=None, nor
     y = np.zeros((B, Cout, Lout), dtype=np.float32) if y_init is None else _f32(y_init).copy()
     st = np.zeros((B, Cout, 2), dtype=np.float32) if want_stats else None
     ln = None if lens is None else np.ascontiguousarray(lens, dtype=np.int32)
-    _err_call(lib.kx_test_conv1d_full, device, _ptr(x), B, Cin, L, _ptr(ln), 1 if pad_ld else 0, _ptr(w), _ptr(_f32(bias)),
+    _err_call(lib.kx_test_conv1d_full, device, _ptr(x), B, Cin, L, _ptr(ln), (1 if pad_ld else 0) | (2 if flat else 0), _ptr(w), _ptr(_f32(bias)),
               Cout, k, pad, dil, act, float(slope), _ptr(_f32(alpha)), _ptr(_f32(norm)), _ptr(_f32(resid)),
               0 if y_init is None else 1, float(out_mul), float(out_div), _ptr(y), _ptr(st), mode)
     return (y, st) if want_stats else y

@@ -308,7 +308,8 @@ def test_s16_form_borders_against_float64(Cin, Cout, L, d, pad_ld):
         conv[i, :, :n] = F.conv1d(xt[i:i + 1, :, :n], torch.from_numpy(w).double(), torch.from_numpy(b).double(),
                                   padding=p, dilation=d).numpy()[0]
     valid = np.arange(L)[None, None, :] < lens[:, None, None]
-    kw = dict(pad=p, dil=d, act=2, alpha=alpha, norm=norm, lens=lens, pad_ld=pad_ld)
+    # (every second case through the flat tile list the model uses for batches, the others through the dense grid)
+    kw = dict(pad=p, dil=d, act=2, alpha=alpha, norm=norm, lens=lens, pad_ld=pad_ld, flat=(L % 4 == 1))
     mul = float(np.float32(0.70710678))
     for mode in (1, 3):
         # (1) plain store; columns past an utterance's length are not written
@@ -332,6 +333,40 @@ def test_s16_form_borders_against_float64(Cin, Cout, L, d, pad_ld):
         assert np.abs(np.where(valid, y - conv * mul, 0.0)).max() < 3e-5, mode
         y64 = np.where(valid, y.astype(np.float64), 0.0)
         assert np.abs(st[..., 0] - y64.sum(axis=2)).max() < 2e-3 * max(1.0, np.sqrt(L) / 10), mode
+
+
+@pytest.mark.parametrize("k,d,act,C,L", [(11, 3, 2, 128, 20000), (11, 1, 2, 256, 6000), (7, 5, 2, 128, 20000), (3, 1, 2, 256, 6000),
+                                          (3, 1, 1, 1024, 900), (5, 1, 0, 128, 9000), (11, 1, 2, 128, 700)])
+def test_flat_tile_list_gives_the_same_bits_as_the_dense_grid(k, d, act, C, L):
+    """A ragged batch through the flat list of live tiles (ConvArgs::tile_prefix: what Model::conv hands the direct-A kernels
+    when B > 1) against the (longest length) x B grid with early-exit workgroups: same bits in the stored values and in
+    the fused statistics, on chip-filling and on small grids, for every unrolled form (S16, W2, leaky k = 3) and the
+    run-time form."""
+    from kokorox_amd import hip_koko as hk
+    rng = np.random.default_rng(k * 31 + C)
+    B = 8
+    p = d * (k - 1) // 2
+    lens = np.array([L, L // 3, (2 * L) // 3, 1, L - 1, L // 2 + 17, 129, (3 * L) // 4], dtype=np.int32)
+    x = rng.standard_normal((B, C, L), dtype=np.float32)
+    w = (rng.standard_normal((C, C, k), dtype=np.float32) / np.sqrt(C * k)).astype(np.float32)
+    b = rng.standard_normal(C, dtype=np.float32)
+    norm = rng.standard_normal((3, B, C), dtype=np.float32)
+    norm[1] = 1.0 + 0.2 * norm[1]
+    alpha = (rng.random(C, dtype=np.float32) + 0.5).astype(np.float32)
+    res = rng.standard_normal((B, C, L), dtype=np.float32)
+    kw = dict(pad=p, dil=d, act=act, slope=0.2, lens=lens, pad_ld=True)
+    if act:
+        kw.update(alpha=alpha, norm=norm)
+    for mode in (1, 3):
+        y0, s0 = hk.conv1d_full(x, w, b, resid=res, want_stats=True, mode=mode, **kw)
+        y1, s1 = hk.conv1d_full(x, w, b, resid=res, want_stats=True, mode=mode, flat=True, **kw)
+        np.testing.assert_array_equal(y0, y1)
+        np.testing.assert_array_equal(s0, s1)
+        assert np.isfinite(y1).all() and np.abs(y1).max() > 0
+        run = rng.standard_normal((B, C, L), dtype=np.float32)
+        z0 = hk.conv1d_full(x, w, b, resid=res, y_init=run, out_div=3.0, mode=mode, **kw)
+        z1 = hk.conv1d_full(x, w, b, resid=res, y_init=run, out_div=3.0, mode=mode, flat=True, **kw)
+        np.testing.assert_array_equal(z0, z1)
 
 
 @pytest.mark.parametrize("mode", MODES)
