@@ -400,7 +400,10 @@ def main():
     ap.add_argument("--durations", default="pinned", choices=["pinned", "free"],
                     help="free = the timed steps run on the predicted (ragged) durations: a profiling mode (rocprof of the "
                          "ragged step, tools/ragged_profile.sh); the headline is the pinned workload")
-    ap.add_argument("--serve-models", type=int, default=2, help="models per GPU behind the serving leg's dispatcher")
+    ap.add_argument("--serve-models", type=int, default=1,
+                    help="models per GPU behind the serving leg's dispatcher (1: the dispatcher already keeps the next batch's "
+                         "forward behind the current one with two workers per model; a second MODEL on the GPU measured slower, "
+                         "p99 1 s: its 1024-thread LSTM workgroups starve behind the other stream's conv workgroups, DESIGN.md)")
     ap.add_argument("--latency-b1", type=int, default=50, help="batch-1 calls timed for the latency_b1 block (configs[1]; 0 = skip)")
     ap.add_argument("--replicas", type=int, default=0,
                     help="single-process form: N models from kx_create_replicas, one host thread each (instead of torchrun)")
@@ -692,8 +695,6 @@ def main():
         }
         out["serve"] = None
         if world == 1 and a.serve:
-            # two models on the GPU: while one batch is in its host-side phases (copies, the mid-forward sync, packing) or
-            # in its recurrences, the other model's batch keeps the chip busy (two in-flight batches per GPU)
             serve_models = [model] + [hk.HipKoko.new(blob_path, device=dev_index) for _ in range(max(0, a.serve_models - 1))]
             try:
                 out["serve"] = serve_leg(serve_models)

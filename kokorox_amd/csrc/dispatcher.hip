@@ -14,17 +14,20 @@ using kx::dispatch::Request;
 // One batched forward on a model: requests of every kind / format in one HostCall (per-utterance kinds, formats, keys).
 struct ModelBackend {
     using Handle = kx_model;
+    struct Out {
+        void* buf = nullptr;  // the packed batch in one pooled page-locked buffer (utterances back to back)
+        std::vector<int64_t> bytes, samples;
+    };
     static int n_voices(kx_model* h) { return h->m->n_voices(); }
-    static int run_batch(kx_model* h, std::vector<Request*>& batch) {
+    static int forward(kx_model* h, std::vector<Request*>& batch, Out& o) {
         const int B = (int)batch.size();
         size_t stride = 0;
         int mm = 1;
-        bool any_voice = false, any_style = false, mixed_format = false;
+        bool any_voice = false, mixed_format = false;
         for (Request* r : batch) {
             stride = r->ids.size() > stride ? r->ids.size() : stride;
             mm = r->n_mix > mm ? r->n_mix : mm;
             any_voice = any_voice || r->kind != 0;
-            any_style = any_style || r->kind == 0;
             mixed_format = mixed_format || r->format != batch[0]->format;
         }
         std::vector<int64_t> ids((size_t)B * stride, 0);
@@ -45,8 +48,9 @@ struct ModelBackend {
             speeds[b] = r.speed;
             seeds[b] = r.seed;
         }
-        void* out = nullptr;
-        std::vector<int64_t> out_bytes(B, 0), out_samples(B, 0);
+        o.buf = nullptr;
+        o.bytes.assign(B, 0);
+        o.samples.assign(B, 0);
         int rc = KX_ERR_DEVICE;
         std::string err;
         {
@@ -66,8 +70,8 @@ struct ModelBackend {
                 } else {
                     hc.styles = styles.data();
                 }
-                M.infer_host_ex(ids.data(), (int64_t)stride, lens.data(), B, speeds.data(), B, 0, 0, hc, &out, out_bytes.data(),
-                                out_samples.data());
+                M.infer_host_ex(ids.data(), (int64_t)stride, lens.data(), B, speeds.data(), B, 0, 0, hc, &o.buf, o.bytes.data(),
+                                o.samples.data());
                 rc = KX_OK;
             } catch (const kx::Error& e) {
                 rc = e.code;
@@ -76,24 +80,31 @@ struct ModelBackend {
                 err = e.what();
             }
         }
-        int64_t off = 0;
-        for (int b = 0; b < B; ++b) {
-            Request* r = batch[b];
+        for (Request* r : batch) {
             r->rc = rc;
             r->err = err;
-            if (rc == KX_OK) {
-                r->out_bytes = out_bytes[b];
-                r->out_samples = out_samples[b];
-                r->out = malloc((size_t)(out_bytes[b] > 0 ? out_bytes[b] : 1));
-                if (r->out)
-                    memcpy(r->out, static_cast<char*>(out) + off, (size_t)out_bytes[b]);
-                else
-                    r->rc = KX_ERR_DEVICE;
-                off += out_bytes[b];
-            }
         }
-        kx::host_out_free(out);  // (the batch buffer is one of the pooled page-locked ones)
         return rc;
+    }
+    // Every request gets a pointer INTO the batch's page-locked buffer (no per-request malloc + copy of a megabyte each: that
+    // was ~5 ms per batch of host time); the buffer goes back to the pool when the last of them has been freed
+    // (kx_free_audio / kx_free_packed -> host_out_free).
+    static void distribute(std::vector<Request*>& batch, Out& o) {
+        const int B = (int)batch.size();
+        std::vector<void*> parts((size_t)B);
+        int64_t off = 0;
+        for (int b = 0; b < B; ++b) {
+            parts[(size_t)b] = static_cast<char*>(o.buf) + off;
+            off += o.bytes[(size_t)b];
+        }
+        kx::host_out_share(o.buf, parts.data(), B);
+        for (int b = 0; b < B; ++b) {
+            Request* r = batch[(size_t)b];
+            r->out = parts[(size_t)b];
+            r->out_bytes = o.bytes[(size_t)b];
+            r->out_samples = o.samples[(size_t)b];
+        }
+        o.buf = nullptr;
     }
 };
 

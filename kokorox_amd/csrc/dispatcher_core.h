@@ -4,11 +4,11 @@
 //
 // The reference serves every request through one `Mutex<Session>` (kokorox/src/onn/ort_koko.rs:78; callers
 // kokorox-openai/src/lib.rs:370-439, kokorox-websocket/src/lib.rs:657-668): N clients = N sequential runs.
-// Here any number of OS threads call submit*(); one worker thread per model (= per GPU) takes requests off ONE shared
-// queue and runs them as one batched forward:
-//   * a worker that finds work waits at most `max_wait_us` after the oldest request's arrival for company (unless the
-//     queue already holds a full batch for every idle worker), then takes its SHARE of the queue: ceil(queued / idle
-//     workers), at most `max_batch`.  32 requests waiting in front of 8 idle GPUs become 8 batches of 4, not one batch
+// Here any number of OS threads call submit*(); worker threads of each model (= each GPU) take requests off ONE shared
+// queue and run them as one batched forward:
+//   * a worker whose model is free and that finds work waits at most `max_wait_us` after the oldest request's arrival for
+//     company (unless the queue already holds a full batch for every free model), then takes its SHARE of the queue:
+//     ceil(queued / free models), at most `max_batch`.  32 requests waiting in front of 8 idle GPUs become 8 batches of 4, not one batch
 //     of 32 on one GPU beside seven idle ones; a single worker that frees up while the others are busy takes up to a
 //     whole batch (the reference's config 5: kokorox-openai, 32 clients over 8 GPUs).
 //   * a request names its voice either as the 256-float style row (what `mix_styles` returns, koko.rs:1255-1306) or as
@@ -23,10 +23,15 @@
 //     fail alone report it; a DEVICE-class failure (HIP error, recurrence hand-off time-out) is retried ONCE as a batch —
 //     never B times on a GPU that may be faulted — and if it fails again every request of the batch reports it.
 //
+//   * two worker threads per model alternate, so that the host side of a finished batch (handing every client its bytes,
+//     waking it) runs beside the NEXT batch's forward; a worker takes requests only when its model's GPU phase is free,
+//     so what arrives during a forward accumulates into the next batch.
+//
 // Backend contract:
-//   using Handle = ...;                                                   one per model
-//   static int run_batch(Handle*, std::vector<dispatch::Request*>&);      fills rc / err (and out* on success) of EVERY
-//                                                                         request, returns the batch's status
+//   using Handle = ...;  using Out = ...;                                 one Handle per model; Out = a finished batch's packed result
+//   static int forward(Handle*, std::vector<dispatch::Request*>&, Out&);  the batched forward: fills rc / err of EVERY request
+//                                                                         (and Out on success), returns the batch's status
+//   static void distribute(std::vector<dispatch::Request*>&, Out&);       gives every request its out / out_bytes / out_samples
 //   static int n_voices(Handle*);                                         rows of the model's voice table (0 = none)
 #pragma once
 #include <chrono>
@@ -77,7 +82,8 @@ struct Core {
     std::condition_variable cv_work, cv_done, cv_quiet;
     std::deque<Request*> queue;
     bool stop = false;
-    int idle = 0;    // workers waiting for work (or for company) right now
+    static constexpr int WORKERS_PER_MODEL = 2;
+    std::vector<char> busy;  // per model: a forward is running (its GPU phase); 0 = a worker may start the next batch
     int inside = 0;  // client threads inside submit() (shutdown waits for them before the object goes away)
     std::vector<std::thread> workers;
     int64_t n_requests = 0, n_batches = 0, max_seen_batch = 0, n_replayed = 0, n_retried = 0;
@@ -85,7 +91,8 @@ struct Core {
 
     Core(Handle** ms, int n, int max_b, int wait_us) : models(ms, ms + n), max_batch(max_b), max_wait_us(wait_us) {
         per_model_batches.assign((size_t)n, 0);
-        for (int i = 0; i < n; ++i) workers.emplace_back([this, i] { worker(i); });
+        busy.assign((size_t)n, 0);
+        for (int i = 0; i < n * WORKERS_PER_MODEL; ++i) workers.emplace_back([this, i] { worker(i); });
     }
     Core(const Core&) = delete;
     Core& operator=(const Core&) = delete;
@@ -105,58 +112,73 @@ struct Core {
     }
     ~Core() { shutdown(); }
 
+    // Two workers per model alternate: while one hands a finished batch's results to its clients (host work: copies, wake-ups),
+    // the other already runs the next batch's forward.  `busy[m]` is the model's GPU phase: a worker takes requests off the
+    // queue only when its model is free, so requests that arrive during a forward accumulate into the next batch.
     void worker(int wi) {
-        Handle* h = models[(size_t)wi];
+        const size_t m = (size_t)wi / WORKERS_PER_MODEL;
+        Handle* h = models[m];
         for (;;) {
             std::vector<Request*> batch;
             bool more;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                ++idle;
-                cv_work.wait(lk, [&] { return stop || !queue.empty(); });
-                if (stop && queue.empty()) {
-                    --idle;
-                    return;
-                }
-                // work is here: give others a short chance to join, unless every idle worker already has a full batch
-                while (!stop && !queue.empty() && (long)queue.size() < (long)max_batch * idle) {
-                    const auto deadline = queue.front()->t_submit + std::chrono::microseconds(max_wait_us);
-                    const auto now = std::chrono::steady_clock::now();
-                    if (now >= deadline) break;
+                for (;;) {
+                    // (after `stop` the queue is still drained: a worker leaves only when nothing is waiting)
+                    cv_work.wait(lk, [&] { return (stop && queue.empty()) || (!queue.empty() && !busy[m]); });
+                    if (queue.empty()) return;
+                    // work is here and this model is free: give others a short chance to join, unless every free model
+                    // already has a full batch waiting
+                    bool go = true;
+                    while (!stop && !queue.empty() && !busy[m] && (long)queue.size() < (long)max_batch * free_models()) {
+                        const auto deadline = queue.front()->t_submit + std::chrono::microseconds(max_wait_us);
+                        const auto now = std::chrono::steady_clock::now();
+                        if (now >= deadline) break;
 #if defined(__SANITIZE_THREAD__)
-                    // gcc 11's ThreadSanitizer does not intercept pthread_cond_clockwait (what a steady-clock wait becomes)
-                    // and then reports the mutex as locked twice; a system-clock wait goes through pthread_cond_timedwait
-                    cv_work.wait_until(lk, std::chrono::system_clock::now() + (deadline - now));
+                        // gcc 11's ThreadSanitizer does not intercept pthread_cond_clockwait (what a steady-clock wait becomes)
+                        // and then reports the mutex as locked twice; a system-clock wait goes through pthread_cond_timedwait
+                        cv_work.wait_until(lk, std::chrono::system_clock::now() + (deadline - now));
 #else
-                    cv_work.wait_until(lk, deadline);
+                        cv_work.wait_until(lk, deadline);
 #endif
+                    }
+                    if (queue.empty() || busy[m]) go = false;  // (the sibling worker, or another model's, was quicker)
+                    if (go) break;
                 }
-                // this worker's share of what is waiting (the other idle workers wake up on the same notify and take theirs)
-                long take = ((long)queue.size() + idle - 1) / idle;
+                // this model's share of what is waiting (the other free models' workers wake up on the same notify)
+                const long fm = free_models();
+                long take = ((long)queue.size() + fm - 1) / fm;
                 take = take > max_batch ? max_batch : take;
-                --idle;
                 while (!queue.empty() && (long)batch.size() < take) {
                     batch.push_back(queue.front());
                     queue.pop_front();
                 }
-                if (batch.empty()) continue;  // (another worker was quicker)
+                busy[m] = true;
                 n_batches += 1;
-                per_model_batches[(size_t)wi] += 1;
+                per_model_batches[m] += 1;
                 n_requests += (int64_t)batch.size();
                 if ((int64_t)batch.size() > max_seen_batch) max_seen_batch = (int64_t)batch.size();
                 more = !queue.empty();
             }
-            if (more) cv_work.notify_all();  // (what is left is for the other idle workers)
-            int rc = run_retrying(h, batch);
-            if (rc == KX_ERR_INVALID && batch.size() > 1) {
+            if (more) cv_work.notify_all();  // (what is left is for the other free models)
+            typename Backend::Out out;
+            int rc = forward_retrying(h, batch, out);
+            const bool replay = rc == KX_ERR_INVALID && batch.size() > 1;
+            if (replay) {
                 // per-request isolation: only the requests that fail alone report the failure
                 for (Request* r : batch) {
                     std::vector<Request*> one{r};
-                    run_retrying(h, one);
+                    typename Backend::Out o1;
+                    if (forward_retrying(h, one, o1) == KX_OK) Backend::distribute(one, o1);
                 }
-                std::lock_guard<std::mutex> lk(mu);
-                n_replayed += (int64_t)batch.size();
             }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                busy[m] = false;  // the model's GPU phase is over: its other worker may start the next batch
+                if (replay) n_replayed += (int64_t)batch.size();
+            }
+            cv_work.notify_all();
+            if (rc == KX_OK) Backend::distribute(batch, out);  // host work, beside the next batch's forward
             {
                 std::lock_guard<std::mutex> lk(mu);
                 for (Request* r : batch) r->done = true;
@@ -165,12 +187,18 @@ struct Core {
         }
     }
 
+    long free_models() const {  // (under mu) at least 1: the caller's own model is free when this is asked
+        long n = 0;
+        for (char b : busy) n += b ? 0 : 1;
+        return n > 0 ? n : 1;
+    }
+
     // One forward; a DEVICE-class failure gets one more try as the same batch (a hand-off time-out switches the model to its
     // fall-back recurrence); a second failure is what every request of the batch reports.
-    int run_retrying(Handle* h, std::vector<Request*>& batch) {
-        int rc = Backend::run_batch(h, batch);
+    int forward_retrying(Handle* h, std::vector<Request*>& batch, typename Backend::Out& out) {
+        int rc = Backend::forward(h, batch, out);
         if (rc != KX_ERR_DEVICE) return rc;
-        rc = Backend::run_batch(h, batch);
+        rc = Backend::forward(h, batch, out);
         std::lock_guard<std::mutex> lk(mu);
         n_retried += 1;
         return rc;

@@ -227,6 +227,9 @@ void launch_pack_audio(const float* audio, long audio_ld, const int* frames, int
 // of per-utterance pageable copies); host_out_free also accepts plain malloc'd pointers (dispatcher results).
 void* host_out_alloc(size_t bytes);
 void host_out_free(void* p);
+// n pointers into one host_out_alloc'd buffer handed to n owners: each is released with host_out_free, the buffer goes back
+// to the pool with the last one (parts[0] may be the buffer's own address)
+void host_out_share(void* base, void* const* parts, int n);
 void launch_fill_style_rows(float* dst, long bs, int ld, int row0, const float* styles, int style_off,
                             const int* lens, int B, int Tmax, hipStream_t s);
 void launch_copy_rows(const float* src, long sbs, int sld, float* dst, long dbs, int dld, int rows, LenMap len,

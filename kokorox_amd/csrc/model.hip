@@ -1605,6 +1605,8 @@ struct HostPool {
     std::mutex mu;
     std::map<void*, size_t> cap;             // every live pinned buffer -> capacity
     std::multimap<size_t, void*> free_list;  // idle ones by capacity
+    std::map<void*, void*> alias;            // pointer handed to an owner -> the shared buffer it lies in (host_out_share)
+    std::map<void*, int> refs;               // shared buffer -> owners still holding a part
     size_t idle_bytes = 0;
     static constexpr size_t kMaxIdle = size_t(1) << 30;
     ~HostPool() {
@@ -1642,12 +1644,29 @@ void* host_out_alloc(size_t bytes) {
     return p;
 }
 
+void host_out_share(void* base, void* const* parts, int n) {
+    if (!base || n <= 0) return;
+    HostPool& P = host_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.refs[base] = n;
+    for (int i = 0; i < n; ++i) P.alias[parts[i]] = base;
+}
+
 void host_out_free(void* p) {
     if (!p) return;
     HostPool& P = host_pool();
     size_t c = 0;
     {
         std::lock_guard<std::mutex> lk(P.mu);
+        auto al = P.alias.find(p);
+        if (al != P.alias.end()) {  // one part of a shared batch buffer: the buffer itself goes when the last part has gone
+            void* base = al->second;
+            P.alias.erase(al);
+            auto rf = P.refs.find(base);
+            if (rf != P.refs.end() && --rf->second > 0) return;
+            if (rf != P.refs.end()) P.refs.erase(rf);
+            p = base;
+        }
         auto it = P.cap.find(p);
         if (it != P.cap.end()) {
             c = it->second;

@@ -51,10 +51,20 @@ void expected(const Request& r, std::vector<unsigned char>& out) {
 
 struct StubBackend {
     using Handle = StubHandle;
+    struct Out {
+        std::vector<std::vector<unsigned char>> parts;  // the "packed batch": one entry per request
+    };
     static int n_voices(StubHandle* h) { return h->m->voices.load(); }
-    static int run_batch(StubHandle* h, std::vector<Request*>& batch) {
+    static int forward(StubHandle* h, std::vector<Request*>& batch, Out& o) {
         StubModel& M = *h->m;
-        std::lock_guard<std::mutex> lk(M.mu);
+        std::unique_lock<std::mutex> lk(M.mu, std::try_to_lock);
+        if (!lk.owns_lock()) {  // the dispatcher's busy flag must have kept the sibling worker out
+            for (Request* r : batch) {
+                r->rc = KX_ERR_STATE;
+                r->err = "stub: two forwards on one model at once";
+            }
+            return KX_ERR_STATE;
+        }
         const long nth = ++M.batches;
         std::this_thread::sleep_for(std::chrono::microseconds(M.sleep_us));
         int rc = KX_OK;
@@ -69,19 +79,27 @@ struct StubBackend {
                     err = "stub: poison request";
                 }
         }
+        o.parts.clear();
         for (Request* r : batch) {
             r->rc = rc;
             r->err = err;
             if (rc == KX_OK) {
-                std::vector<unsigned char> e;
-                expected(*r, e);
-                r->out = malloc(e.size() ? e.size() : 1);
-                memcpy(r->out, e.data(), e.size());
-                r->out_bytes = (int64_t)e.size();
-                r->out_samples = (int64_t)r->ids.size() * 10;
+                o.parts.emplace_back();
+                expected(*r, o.parts.back());
             }
         }
         return rc;
+    }
+    static void distribute(std::vector<Request*>& batch, Out& o) {
+        std::this_thread::sleep_for(std::chrono::microseconds(150));  // host work beside the next forward
+        for (size_t i = 0; i < batch.size(); ++i) {
+            Request* r = batch[i];
+            const std::vector<unsigned char>& e = o.parts[i];
+            r->out = malloc(e.size() ? e.size() : 1);
+            memcpy(r->out, e.data(), e.size());
+            r->out_bytes = (int64_t)e.size();
+            r->out_samples = (int64_t)r->ids.size() * 10;
+        }
     }
 };
 
