@@ -10,8 +10,8 @@ for grp in \
  "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_UNALIGNED_STALL" \
  "SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_IFETCH" ; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/pmc_sq_$i -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-utts 0 --free-run 0 --pcie 0 --serve 0 --reduced 0 > $R/gpurun_out/pmc_sq_$i.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/pmc_sq_$i -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-utts 0 --free-run 0 --pcie 0 --serve 0 --reduced 0 --latency-b1 0 > $R/gpurun_out/pmc_sq_$i.log 2>&1
   echo "pass $i done"
 done
 cd $R
-python tools/summarize_pmc_sq.py gpurun_out/pmc_sq_ "${1:-conv1d_f16x3_da_kernel<2, 11, 8>}"
+python tools/summarize_pmc_sq.py gpurun_out/pmc_sq_ "${1:-conv1d_f16x3_da_kernel<2, 11, 6, false, false, true>}"

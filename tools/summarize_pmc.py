@@ -6,7 +6,11 @@ No hand-fed constants: the doubling is CHECKED (not calibrated) on in_stats_kern
 normalises exactly once - the bytes it must read come from the library's own launch accounting (bench.py prints them as
 "in_stats" in its JSON line, which the FETCH_SIZE pass keeps as its stdout).
 
-usage: summarize_pmc.py <fetch_dir> <write_dir> <out.json> <bench stdout of the FETCH pass> <kernel family substring> <mode>
+Per instantiation (round 4): with a `--detail` table of the same workload (bench.py --detail: algorithmic bytes per conv
+shape) the traffic of every kernel of the family is set against the algorithmic bytes of the shapes that kernel runs
+(grouped by tap count and by snake-resblock / other, which is what selects the instantiation).
+
+usage: summarize_pmc.py <fetch_dir> <write_dir> <out.json> <bench stdout of the FETCH pass> <kernel family substring> <mode> [detail.txt]
 """
 import collections
 import csv
@@ -25,7 +29,44 @@ def load(pat):
     return agg
 
 
-def main(fetch_dir, write_dir, out, bench_stdout, family="conv1d_f16x3_kernel<128,", mode="f16x3"):
+def shape_groups(detail_path):
+    """bench.py --detail rows -> {group: algorithmic bytes per step}; group = the instantiation the shape runs on."""
+    g = collections.defaultdict(float)
+    for line in open(detail_path).read().splitlines()[1:]:
+        v = line.split()
+        rows, cin, taps, store = int(v[0]), int(v[1]), int(v[2]), int(v[5])
+        alg = float(v[10]) * 1e9
+        resblock = rows == cin and rows in (128, 256) and taps in (3, 7, 11)
+        if store == 2:
+            key = "da<1, 0, 8> polyphase transposed convs"
+        elif taps == 1:
+            key = "dag / da<0, 0, 8> k = 1"
+        elif resblock:
+            key = f"da<2, {taps}, *> snake resblock convs, {taps} taps"
+        else:
+            key = f"da<1, {taps}, *> / other, {taps} taps"
+        g[key] += alg
+    return g
+
+
+def kernel_group(name):
+    import re
+    m = re.search(r"da_kernel<(\d+), (\d+), (\d+)", name)
+    if m:
+        act, kt = int(m.group(1)), int(m.group(2))
+        if act == 2 and kt in (3, 7, 11):
+            return f"da<2, {kt}, *> snake resblock convs, {kt} taps"
+        if act == 1 and kt == 0:
+            return "da<1, 0, 8> polyphase transposed convs"
+        if kt == 0:
+            return "dag / da<0, 0, 8> k = 1"
+        return f"da<1, {kt}, *> / other, {kt} taps"
+    if "dag" in name:
+        return "dag / da<0, 0, 8> k = 1"
+    return "LDS-DMA forms (conv1d_f16x3_kernel<128,..>)"
+
+
+def main(fetch_dir, write_dir, out, bench_stdout, family="conv1d_f16x3_kernel<128,", mode="f16x3", detail=None):
     f = load(fetch_dir + "/*/*_counter_collection.csv")
     w = load(write_dir + "/*/*_counter_collection.csv")
     fams = family.split("|")  # ("a|b": several name patterns, e.g. the direct-A and the LDS-DMA form of the 128-row conv)
@@ -56,6 +97,25 @@ def main(fetch_dir, write_dir, out, bench_stdout, family="conv1d_f16x3_kernel<12
     }
     res["traffic_bytes_per_launch"] = res["fetch_bytes_per_launch"] + res["write_bytes_per_launch"]
     res["traffic_over_algorithmic"] = res["traffic_bytes_per_launch"] / alg if alg else None
+    if detail:
+        alg_g = shape_groups(detail)
+        per = collections.OrderedDict()
+        for k in sorted(fam, key=lambda k: -(f[k][1] * FETCH_FACTOR + w[k][1])):
+            grp = kernel_group(k)
+            e = per.setdefault(grp, {"kernels": [], "launches": 0, "fetch_bytes": 0.0, "write_bytes": 0.0})
+            e["kernels"].append(k.split("(")[0][-60:])
+            e["launches"] += f[k][0]
+            e["fetch_bytes"] += f[k][1] * 1024 * FETCH_FACTOR
+            e["write_bytes"] += w[k][1] * 1024
+        for grp, e in per.items():
+            e["traffic_bytes"] = e["fetch_bytes"] + e["write_bytes"]
+            a = alg_g.get(grp, 0.0) * steps
+            e["algorithmic_bytes"] = a
+            e["traffic_over_algorithmic"] = e["traffic_bytes"] / a if a else None
+        res["per_instantiation"] = per
+        res["per_instantiation_note"] = ("traffic summed over every launch of the run; algorithmic bytes = bench.py --detail of the same "
+                                         "workload, summed over the shapes each instantiation runs (k = 1 shapes that the LDS-DMA "
+                                         "statistics form runs are counted under 'dag / da<0, 0, 8> k = 1')")
     res["workload"] = {"batch": bench["config"]["batch_per_gpu"], "tokens": bench["config"]["tokens"],
                        "frames": bench["config"]["frames"], "conv_mode": mode}
     json.dump(res, open(out, "w"), indent=1)
@@ -63,4 +123,4 @@ def main(fetch_dir, write_dir, out, bench_stdout, family="conv1d_f16x3_kernel<12
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:7])
+    main(*sys.argv[1:8])
