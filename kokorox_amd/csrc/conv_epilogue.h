@@ -388,28 +388,31 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)
             conv_store_rmw<MT, NT, EB, 3, false, GELU>(a, acc, acc_scale, b, row0, col0, r, h, ncols, stat_slot, stat_scr);
         return;
     }
-    // ST_UPSCATTER: polyphase transposed conv, GEMM row (p, co), column q -> out[co][s*q + p - pad]
+    // ST_UPSCATTER: polyphase transposed conv, GEMM row = co * s + p (PHASE FASTEST), column q -> out[co][s*q + p - pad].
+    // With the phase fastest, the s phases of an output line are rows of ONE wave, stored by back-to-back instructions, so
+    // the line is whole in L2 when it leaves for HBM.  (Rows (p, co) put every phase in another row tile = another
+    // workgroup: lines left L2 partly written, and the PMC counters showed 2.6x the algorithmic writes plus the
+    // read-modify-write fetches, 3.1x the algorithmic traffic in all: profiles/r04_pmc_conv_traffic_f16x3.json.)
     const int rows_here = MT * 32;
     const int q_lo = col0, q_hi = col0 + NT * 32 - 1;
-    // interior block: all rows valid, all columns valid, every phase of every column lands inside [0, Lout), and no
-    // row of the block wraps the (p, co) split more than once -> branch-free form with scalar row terms
+    // interior block: all rows valid, all columns valid, every phase of every column lands inside [0, Lout) ->
+    // branch-free form with scalar row terms (row / s by a 16-bit reciprocal: exact for s <= 12 and rows < 8192)
     const bool interior = row0 + rows_here <= a.Cout && q_hi < ncols && a.up_s * q_lo - a.up_pad >= 2 &&
-                          a.up_s * q_hi + (a.up_s - 1) - a.up_pad < Lout && a.up_cout >= rows_here;
+                          a.up_s * q_hi + (a.up_s - 1) - a.up_pad < Lout && a.up_s <= 12 && a.Cout < 8192;
     if (interior) {
         const buf_rsrc ybuf = make_buf(a.y + (long)b * a.y_bs);
         const buf_rsrc rbuf = make_buf(a.resid ? a.resid + (long)b * a.r_bs : a.y);
         const bool has_res = a.resid != nullptr;
+        const unsigned inv_s = (65536u + (unsigned)a.up_s - 1u) / (unsigned)a.up_s;
         const int brow = row0 + r + 32 * h;  // bias of the wave's rows, one per lane (row -> co below)
-        const int bp = brow / a.up_cout;
-        const float bias_lane = a.bias ? a.bias[brow - bp * a.up_cout] : 0.f;
+        const float bias_lane = a.bias ? a.bias[((unsigned)brow * inv_s) >> 16] : 0.f;
         unsigned qoff[NT];  // byte offset of column q inside an output row: 4 * s * q
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) qoff[nt] = 4u * (unsigned)(a.up_s * (col0 + nt * 32 + r));
-        const int p0 = row0 / a.up_cout, co0 = row0 - p0 * a.up_cout;  // (wave-uniform)
         // rows come in pairs (c, c + 4) split over the half-waves; their uniform byte terms for y and resid
         auto row_terms = [&](int d, unsigned& yt, unsigned& rt) {
-            int co = co0 + d, pp = p0;
-            if (co >= a.up_cout) { co -= a.up_cout; ++pp; }
+            const int row = row0 + d;  // (wave-uniform)
+            const int co = (int)(((unsigned)row * inv_s) >> 16), pp = row - co * a.up_s;
             const int t = pp - a.up_pad + a.up_off;
             yt = 4u * (unsigned)(co * a.y_ld + t);
             rt = 4u * (unsigned)(co * a.r_ld + t);
@@ -457,8 +460,8 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)
         for (int e = 0; e < 16; ++e) {
             const int row = row0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
             if (row >= a.Cout) continue;
-            const int p = row / a.up_cout;
-            const int co = row - p * a.up_cout;
+            const int co = row / a.up_s;
+            const int p = row - co * a.up_s;
             const float bv = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {

@@ -644,7 +644,7 @@ __global__ void pack_convT16_kernel(const float* w, _Float16* dst, int Cin, int 
         const int row = (int)q * BM + m, ci = ch * CK16 + hh * 8 + j8;
         float v = 0.f;
         if (row < rows && ci < Cin) {
-            const int p = row / Cout, co = row % Cout;
+            const int sdiv = sd, co = row / sdiv, p = row % sdiv;  // GEMM row = co * s + p (phase fastest: conv_epilogue.h, ST_UPSCATTER)
             v = w[((long)ci * Cout + co) * k + (tap == 0 ? p + sd : p)] * wscale;
         }
         const _Float16 hi = (_Float16)v;

@@ -212,7 +212,7 @@ void launch_pack_conv(const PackSrc& src, float* dst, int Cout, int Cin, int K, 
 
 // ConvTranspose1d(Cin, Cout, k = 2s, stride s, padding (k-s)/2): out[co][s*q' + p - pad] =
 // sum_ci W[ci][co][p] * x[ci][q'] + W[ci][co][p+s] * x[ci][q'-1].  As a conv over q' with 2 taps and
-// left padding 1: tap 0 reads x[q'-1] (weight p+s), tap 1 reads x[q'] (weight p); GEMM row = p*Cout + co.
+// left padding 1: tap 0 reads x[q'-1] (weight p+s), tap 1 reads x[q'] (weight p); GEMM row = co*s + p.
 __global__ void pack_convT_kernel(const float* w, float* dst, int Cin, int Cout, int s, int BM, long total) {
     const int n_chunks = (Cin + CONV_CK - 1) / CONV_CK;
     const int rows = s * Cout, k = 2 * s;
@@ -225,7 +225,7 @@ __global__ void pack_convT_kernel(const float* w, float* dst, int Cin, int Cout,
         const int row = (int)q * BM + m, ci = ch * CONV_CK + cil;
         float v = 0.f;
         if (row < rows && ci < Cin) {
-            const int p = row / Cout, co = row % Cout;
+            const int sdiv = s, co = row / sdiv, p = row % sdiv;  // GEMM row = co * s + p (phase fastest: conv_epilogue.h, ST_UPSCATTER)
             v = w[((long)ci * Cout + co) * k + (j == 0 ? p + s : p)];
         }
         dst[e] = v;
