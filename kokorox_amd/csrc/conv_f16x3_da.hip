@@ -1106,20 +1106,28 @@ static void launch_da_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s
 #ifdef KX_DA_S16
 // The S16 forms (conv_f16x3_da_s16.hip defines KX_DA_S16 and includes this file).
 // Shapes the S16 form takes (and conv16_pick_tile gives 64-column statistics slots): snake resblock convs with 11 taps and an even
-// number of 16-channel chunks.  KX_DA_S16=0 switches the form off.  (The 7-tap convs were measured on it too: the big launches
-// -3 %, the dilated ones +3 %, no net gain -- profiles/r03_s16_form.txt -- and are not instantiated.)
+// number of 16-channel chunks, and (round 4) the un-dilated 7-tap ones.  KX_DA_S16=0 switches the form off, 2 keeps it to 11 taps.
 bool conv16_da_s16_shape(int BM, int K, int dil, int stride, int act, int n_chunks16, bool merged, bool prec1) {
     static const int on = getenv("KX_DA_S16") ? atoi(getenv("KX_DA_S16")) : 1;
     static const int da = getenv("KX_DA") ? atoi(getenv("KX_DA")) : 1;
     static const int st = getenv("KX_DA_STATIC") ? atoi(getenv("KX_DA_STATIC")) : 1;
-    return on && da && st && BM == 128 && stride == 1 && !merged && !prec1 && act == ACT_SNAKE && K == 11 && (K - 1) * dil <= 64 &&
+    // 11 taps: always.  7 taps: the un-dilated launches only (measured: the big 7-tap launches gain 3 % on this form, the
+    // dilated ones lose 3 %: profiles/r03_s16_form.txt; KX_DA_S16=2 keeps the 7-tap convs off it).  The choice depends on the
+    // layer's shape alone, never on the batch, so an utterance's bits do not depend on what it is batched with.
+    const bool taps = K == 11 || (K == 7 && dil == 1 && on == 1);
+    return on && da && st && BM == 128 && stride == 1 && !merged && !prec1 && act == ACT_SNAKE && taps && (K - 1) * dil <= 64 &&
            n_chunks16 >= 2 && (n_chunks16 & 1) == 0;
 }
 void launch_conv1d_f16x3_da_s16(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn) {
     KX_REQUIRE(conv16_da_s16_shape(128, a.K, a.dil, a.stride, a.act, a.n_chunks16, a.merge_T > 0, a.prec1 != 0), "conv1d f16x3 da s16: launch not eligible");
     KX_REQUIRE(bn == 192 || bn == 128, "conv1d f16x3 da s16: tile of 192 or 128 columns");
-    if (bn == 192) launch_da_inst<ACT_SNAKE, 11, 6>(a, B, max_cols, s);
-    else launch_da_inst<ACT_SNAKE, 11, 4>(a, B, max_cols, s);
+    if (a.K == 11) {
+        if (bn == 192) launch_da_inst<ACT_SNAKE, 11, 6>(a, B, max_cols, s);
+        else launch_da_inst<ACT_SNAKE, 11, 4>(a, B, max_cols, s);
+    } else {
+        if (bn == 192) launch_da_inst<ACT_SNAKE, 7, 6>(a, B, max_cols, s);
+        else launch_da_inst<ACT_SNAKE, 7, 4>(a, B, max_cols, s);
+    }
 }
 #elif defined(KX_DA_W2)
 // The W2 forms (conv_f16x3_da_w2.hip defines KX_DA_W2 and includes this file): the unrolled forms of the 256-column tile;

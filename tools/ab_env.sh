@@ -5,7 +5,7 @@ for round in 1 2; do
   i=0
   for kv in "$@"; do
     i=$((i+1))
-    env $kv timeout -k 10 200 python bench.py --steps 3 --warmup 1 --cpu-utts 0 --free-run 0 --pcie 0 --serve 0 --reduced 0 \
+    env $kv timeout -k 10 200 python bench.py --steps 3 --warmup 1 --cpu-utts 0 --free-run 0 --pcie 0 --serve 0 --reduced 0 --latency-b1 0 \
         --detail gpurun_out/${tag}_${i}_$round.txt > gpurun_out/${tag}_${i}_$round.json 2> gpurun_out/${tag}_${i}_$round.err || exit 1
     python - <<PY
 import json

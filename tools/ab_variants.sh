@@ -7,7 +7,7 @@ for round in 1 2; do
   for v in "$@"; do
     lib=kokorox_amd/lib/variants/lib_$v.so
     [ "$v" = main ] && lib=kokorox_amd/lib/libkokorox_hip.so
-    KX_LIB=$lib timeout -k 10 200 python bench.py --steps 3 --warmup 1 --cpu-utts 0 --free-run 0 --pcie 0 --serve 0 --reduced 0 \
+    KX_LIB=$lib timeout -k 10 200 python bench.py --steps 3 --warmup 1 --cpu-utts 0 --free-run 0 --pcie 0 --serve 0 --reduced 0 --latency-b1 0 \
         --detail gpurun_out/${tag}_${v}_$round.txt > gpurun_out/${tag}_${v}_$round.json 2> gpurun_out/${tag}_${v}_$round.err || exit 1
     python - <<PY
 import json
