@@ -79,16 +79,20 @@ void launch_embed(const int64_t* ids, long ids_stride, const float* table, int C
 }
 
 // ---- channel layer-norm -------------------------------------------------------------------
-// 64 time columns x 16 channel groups per workgroup (1024 threads); reads are coalesced along time.
-// Each thread keeps its CPT = C/16 channel values in registers, so the tensor is read once:
-// mean (LDS reduce over the 16 groups) -> centred sum of squares (reduce) -> normalise + write.
+// 16 time columns x 64 channel groups per workgroup (1024 threads: a wave = 16 columns x 4 groups); reads are 64-byte
+// segments along time.  Each thread keeps its CPT = C/64 channel values in registers, so the tensor is read once:
+// mean (shuffle over the wave's 4 groups, LDS over the 16 waves) -> centred sum of squares (same) -> normalise + write.
+// Every user is on the token axis (T <= 512): 16-column workgroups give 9 workgroups per utterance at T = 130 where the
+// former 64-column ones gave 3 - at batch 1 each of the 30 layer norms of a forward ran on three CUs (22 us each on the
+// critical path).  The geometry is the same for every batch size, so an utterance's bits do not depend on the batch.
 template <int CPT>
 __global__ __launch_bounds__(1024) void layernorm_ch_kernel(const float* x, float* y, long bs, int ld, int C,
                                                             LenMap len, float eps, int mode, const float* g,
                                                             const float* be, int g_bs, float leaky) {
-    __shared__ float red[16][64];
-    const int tx = threadIdx.x & 63, cg = threadIdx.x >> 6;
-    const int b = blockIdx.y, t = blockIdx.x * 64 + tx;
+    __shared__ float red[2][16][16];
+    const int tx = threadIdx.x & 15, cg = threadIdx.x >> 4, wave = threadIdx.x >> 6;
+    const bool wave_lead = (threadIdx.x & 63) < 16;  // lanes whose sums stand for the wave's four groups
+    const int b = blockIdx.y, t = blockIdx.x * 16 + tx;
     const int L = len_of(len, b);
     const bool ok = t < L;
     const float* xb = x + b * bs + (ok ? t : 0);
@@ -96,35 +100,38 @@ __global__ __launch_bounds__(1024) void layernorm_ch_kernel(const float* x, floa
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-        const int c = cg + 16 * i;
+        const int c = cg + 64 * i;
         v[i] = (ok && c < C) ? xb[(long)c * ld] : 0.f;
         s += v[i];
     }
-    red[cg][tx] = s;
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (wave_lead) red[0][wave][tx] = s;
     __syncthreads();
     float tot = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) tot += red[k][tx];
+    for (int k = 0; k < 16; ++k) tot += red[0][k][tx];
     const float mean = tot / (float)C;
-    __syncthreads();
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-        const int c = cg + 16 * i;
+        const int c = cg + 64 * i;
         const float d = (c < C) ? v[i] - mean : 0.f;
         q += d * d;
     }
-    red[cg][tx] = q;
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    if (wave_lead) red[1][wave][tx] = q;
     __syncthreads();
     float qt = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) qt += red[k][tx];
+    for (int k = 0; k < 16; ++k) qt += red[1][k][tx];
     const float rstd = 1.0f / sqrtf(qt / (float)C + eps);
     if (!ok) return;
     float* yb = y + b * bs + t;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-        const int c = cg + 16 * i;
+        const int c = cg + 64 * i;
         if (c >= C) continue;
         float o = (v[i] - mean) * rstd;
         if (mode == LN_AFFINE)
@@ -139,13 +146,13 @@ void launch_layernorm_ch(const float* x, float* y, long bs, int ld, int C, LenMa
                          int mode, const float* g, const float* be, int g_bs, float leaky, hipStream_t s) {
     if (Lmax <= 0) return;
     KX_REQUIRE(C <= 768, "layernorm: at most 768 channels");
-    const dim3 grid((Lmax + 63) / 64, B), block(1024);
+    const dim3 grid((Lmax + 15) / 16, B), block(1024);
     if (C <= 128)
-        hipLaunchKernelGGL(layernorm_ch_kernel<8>, grid, block, 0, s, x, y, bs, ld, C, len, eps, mode, g, be, g_bs, leaky);
+        hipLaunchKernelGGL(layernorm_ch_kernel<2>, grid, block, 0, s, x, y, bs, ld, C, len, eps, mode, g, be, g_bs, leaky);
     else if (C <= 512)
-        hipLaunchKernelGGL(layernorm_ch_kernel<32>, grid, block, 0, s, x, y, bs, ld, C, len, eps, mode, g, be, g_bs, leaky);
+        hipLaunchKernelGGL(layernorm_ch_kernel<8>, grid, block, 0, s, x, y, bs, ld, C, len, eps, mode, g, be, g_bs, leaky);
     else
-        hipLaunchKernelGGL(layernorm_ch_kernel<48>, grid, block, 0, s, x, y, bs, ld, C, len, eps, mode, g, be, g_bs, leaky);
+        hipLaunchKernelGGL(layernorm_ch_kernel<12>, grid, block, 0, s, x, y, bs, ld, C, len, eps, mode, g, be, g_bs, leaky);
     KX_HIP(hipGetLastError());
 }
 
