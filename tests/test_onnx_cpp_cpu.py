@@ -175,3 +175,111 @@ def test_walker_fuzz_under_address_and_ub_sanitizers(files, tmp_path):
         assert p.returncode == 0, so[-2000:] + se[-4000:]
         assert "mutations" in so
     assert " 0 converted" not in outs[-1][0]  # the unmutated full file converts under the sanitizers too
+
+
+def test_less_common_encodings_agree_between_the_two_readers(synth, tmp_path):
+    """Branches the exporter-style files above do not reach, on a model whose other tensors are plain named initialisers:
+    Gemm (transB = 1, bias as third input), a weight that reaches its MatMul through Cast and through Transpose, a weight in
+    a Constant node, ConvInteger with the `_quantized / _scale / _zero_point` naming, DequantizeLinear with block_size,
+    bfloat16 and double initialisers, float16 carried in int32_data, a DataParallel-style 'module.' prefix, a wrapped
+    model ('kmodel.' prefix).  The C++ reader and the Python importer must write the same bytes, and the values must be the
+    expected ones."""
+    t = {k: v.copy() for k, v in synth.items()}
+    nodes, inits = [], []
+    special = {}
+
+    def named(name, a, **kw):
+        inits.append(OX.tensor_bytes(name, a, **kw))
+
+    # 1. Gemm with transB = 1: weight kept as [out, in], bias third input
+    k = "bert_encoder.weight"
+    special[k] = t[k]
+    named("onnx::Gemm_1", t[k])
+    named("onnx::Gemm_2", t["bert_encoder.bias"])
+    nodes.append(OX.node_bytes("Gemm", ["x", "onnx::Gemm_1", "onnx::Gemm_2"], ["g"], name="/bert_encoder/Gemm", attrs={"transB": 1}))
+    # 2. fp16 initialiser -> Cast -> MatMul (weight stored transposed), named bias on the Add
+    k = "predictor.duration_proj.linear_layer.weight"
+    special[k] = t[k].astype(np.float16).astype(np.float32)
+    named("onnx::Cast_3", np.ascontiguousarray(t[k].T).astype(np.float16))
+    nodes.append(OX.node_bytes("Cast", ["onnx::Cast_3"], ["c3"], name="/predictor/duration_proj/linear_layer/Cast", attrs={"to": 1}))
+    nodes.append(OX.node_bytes("MatMul", ["x", "c3"], ["mm3"], name="/predictor/duration_proj/linear_layer/MatMul"))
+    named("predictor.duration_proj.linear_layer.bias", t["predictor.duration_proj.linear_layer.bias"])
+    nodes.append(OX.node_bytes("Add", ["predictor.duration_proj.linear_layer.bias", "mm3"], ["o3"], name="/predictor/duration_proj/linear_layer/Add"))
+    # 3. initialiser stored [out, in] -> Transpose -> MatMul
+    k = "bert.encoder.embedding_hidden_mapping_in.weight"
+    special[k] = t[k]
+    named("onnx::Transpose_4", t[k])
+    nodes.append(OX.node_bytes("Transpose", ["onnx::Transpose_4"], ["t4"], name="/bert/encoder/embedding_hidden_mapping_in/Transpose",
+                               attrs={"perm": [1, 0]}))
+    nodes.append(OX.node_bytes("MatMul", ["x", "t4"], ["mm4"], name="/bert/encoder/embedding_hidden_mapping_in/MatMul"))
+    named("bert.encoder.embedding_hidden_mapping_in.bias", t["bert.encoder.embedding_hidden_mapping_in.bias"])
+    nodes.append(OX.node_bytes("Add", ["mm4", "bert.encoder.embedding_hidden_mapping_in.bias"], ["o4"],
+                               name="/bert/encoder/embedding_hidden_mapping_in/Add"))
+    # 4. a conv weight that lives in a Constant node (attribute tensor), bias anonymous: both through the node name
+    k = "decoder.asr_res.0.weight"
+    special[k] = t[k]
+    cattr = OX._ld(1, b"value") + OX._ld(5, OX.tensor_bytes("", t[k])) + OX._vi(20, 4)
+    nodes.append(OX._ld(2, b"const5") + OX._ld(3, b"/decoder/asr_res.0/Constant") + OX._ld(4, b"Constant") + OX._ld(5, cattr))
+    named("onnx::Conv_6", t["decoder.asr_res.0.bias"])
+    nodes.append(OX.node_bytes("Conv", ["x", "const5", "onnx::Conv_6"], ["o5"], name="/decoder/asr_res.0/Conv"))
+    # 5. ConvInteger, per-tensor scale and zero point
+    k = "decoder.generator.noise_convs.1.weight"
+    sc = np.float32(np.abs(t[k]).max() / 127.0)
+    q = np.clip(np.round(t[k] / sc) + 128, 0, 255).astype(np.uint8)
+    special[k] = ((q.astype(np.float32) - np.float32(128)) * sc).astype(np.float32)
+    named("nc1.weight_quantized", q)
+    named("nc1.weight_scale", np.array(sc, dtype=np.float32))
+    named("nc1.weight_zero_point", np.array(128, dtype=np.uint8))
+    named("decoder.generator.noise_convs.1.bias", t["decoder.generator.noise_convs.1.bias"])
+    nodes.append(OX.node_bytes("ConvInteger", ["xq", "nc1.weight_quantized", "xzp", "nc1.weight_zero_point"], ["ci"],
+                               name="/decoder/generator/noise_convs.1/Conv_quant"))
+    # 6. DequantizeLinear with block_size along axis 1 feeding a Conv
+    k = "decoder.generator.conv_post.weight"
+    a = t[k]  # [22, 128, 7]
+    blk = 32
+    nb = a.shape[1] // blk
+    scb = (np.abs(a.reshape(a.shape[0], nb, blk, a.shape[2])).max(axis=2) / 127.0).astype(np.float32)  # [22, nb, 7]
+    scb[scb == 0] = 1.0
+    qb = np.clip(np.round(a / np.repeat(scb, blk, axis=1)), -127, 127).astype(np.int8)
+    special[k] = (qb.astype(np.float32) * np.repeat(scb, blk, axis=1)).astype(np.float32)
+    named("onnx::DQ_7", qb)
+    named("onnx::DQ_7_s", scb)
+    nodes.append(OX.node_bytes("DequantizeLinear", ["onnx::DQ_7", "onnx::DQ_7_s"], ["dq7"], name="/decoder/generator/conv_post/DequantizeLinear",
+                               attrs={"axis": 1, "block_size": blk}))
+    named("decoder.generator.conv_post.bias", t["decoder.generator.conv_post.bias"])
+    nodes.append(OX.node_bytes("Conv", ["x", "dq7", "decoder.generator.conv_post.bias"], ["o7"], name="/decoder/generator/conv_post/Conv"))
+    # 7. bfloat16 raw, double, float16 in int32_data, 'module.' and 'kmodel.' prefixes
+    k = "predictor.F0_proj.weight"
+    bf = (t[k].view(np.uint32) >> 16).astype(np.uint16)
+    special[k] = (bf.astype(np.uint32) << 16).view(np.float32)
+    named(k, bf, data_type=OX.BFLOAT16)
+    k = "predictor.N_proj.weight"
+    special[k] = t[k]
+    named(k, t[k].astype(np.float64), data_type=OX.DOUBLE)
+    k = "decoder.N_conv.weight"
+    h = t[k].astype(np.float16)
+    special[k] = h.astype(np.float32)
+    inits.append(b"".join(OX._vi(1, int(d)) for d in h.shape) + OX._vi(2, OX.FLOAT16) + OX._ld(8, k.encode())
+                 + OX._ld(5, b"".join(OX._wv(int(x)) for x in h.view(np.uint16).reshape(-1))))  # packed int32_data
+    k = "decoder.F0_conv.weight"
+    special[k] = t[k]
+    named("module." + k, t[k])
+    k = "text_encoder.embedding.weight"
+    special[k] = t[k]
+    named("kmodel." + k, t[k])
+    done = set(special) | {"bert_encoder.bias", "predictor.duration_proj.linear_layer.bias", "bert.encoder.embedding_hidden_mapping_in.bias",
+                           "decoder.asr_res.0.bias", "decoder.generator.noise_convs.1.bias", "decoder.generator.conv_post.bias"}
+    for name, a in t.items():
+        if name not in done:
+            named(name, a)
+    src = str(tmp_path / "exotic.onnx")
+    with open(src, "wb") as f:
+        f.write(OX.model_bytes(nodes, inits))
+    py, cpp = src + ".py.kxw", src + ".cpp.kxw"
+    I.import_onnx(src, py)
+    hk.import_onnx(src, cpp)
+    tp, tc = W.read_blob(py), W.read_blob(cpp)
+    for name, want in special.items():
+        np.testing.assert_array_equal(np.asarray(tp[name]), want.reshape(np.asarray(tp[name]).shape), err_msg=f"python: {name}")
+        np.testing.assert_array_equal(np.asarray(tc[name]), want.reshape(np.asarray(tc[name]).shape), err_msg=f"c++: {name}")
+    assert open(py, "rb").read() == open(cpp, "rb").read()
