@@ -402,8 +402,9 @@ def main():
                          "ragged step, tools/ragged_profile.sh); the headline is the pinned workload")
     ap.add_argument("--serve-models", type=int, default=1,
                     help="models per GPU behind the serving leg's dispatcher (1: the dispatcher already keeps the next batch's "
-                         "forward behind the current one with two workers per model; a second MODEL on the GPU measured slower, "
-                         "p99 1 s: its 1024-thread LSTM workgroups starve behind the other stream's conv workgroups, DESIGN.md)")
+                         "forward behind the current one with two workers per model; a second MODEL on the GPU is 2-6 %% faster until "
+                         "its 1024-thread LSTM workgroups starve behind the other stream's conv workgroups: a 1-2 s stall in one run "
+                         "of three, DESIGN.md section 7)")
     ap.add_argument("--latency-b1", type=int, default=50, help="batch-1 calls timed for the latency_b1 block (configs[1]; 0 = skip)")
     ap.add_argument("--replicas", type=int, default=0,
                     help="single-process form: N models from kx_create_replicas, one host thread each (instead of torchrun)")
