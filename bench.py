@@ -231,9 +231,11 @@ def serve_leg(models, n_clients=32, per_client=48, max_batch=64, max_wait_us=300
         return {"error": errs[:3]}
     closed = _lat_summary(lat, audio, wall)
     closed.update({"clients": n_clients, "batches": st1["batches"] - st0["batches"], "max_batch": st1["max_batch"],
+                   "retried_batches": st1["retried_batches"], "replayed_requests": st1["replayed_requests"],
                    "batches_per_model": [b1 - b0 for b0, b1 in zip(st0["batches_per_model"], st1["batches_per_model"])]})
     progress(f"serve closed loop: {closed['requests']} requests in {wall:.2f} s, {closed['aggregate_rtf']:.0f}x, "
-             f"p50/p99 {closed['latency_p50_ms']:.0f}/{closed['latency_p99_ms']:.0f} ms")
+             f"p50/p99/max {closed['latency_p50_ms']:.0f}/{closed['latency_p99_ms']:.0f}/{closed['latency_max_ms']:.0f} ms, "
+             f"{closed['retried_batches']} batches retried after a device failure")
 
     # ---- open loop: Poisson arrivals at fractions of the closed-loop rate ---------------------------------------------
     open_runs = []
@@ -402,9 +404,8 @@ def main():
                          "ragged step, tools/ragged_profile.sh); the headline is the pinned workload")
     ap.add_argument("--serve-models", type=int, default=1,
                     help="models per GPU behind the serving leg's dispatcher (1: the dispatcher already keeps the next batch's "
-                         "forward behind the current one with two workers per model; a second MODEL on the GPU is 2-6 %% faster until "
-                         "its 1024-thread LSTM workgroups starve behind the other stream's conv workgroups: a 1-2 s stall in one run "
-                         "of three, DESIGN.md section 7)")
+                         "forward behind the current one with two workers per model; several models on one GPU take turns forward by "
+                         "forward and come out 9 %% slower, DESIGN.md section 7)")
     ap.add_argument("--latency-b1", type=int, default=50, help="batch-1 calls timed for the latency_b1 block (configs[1]; 0 = skip)")
     ap.add_argument("--replicas", type=int, default=0,
                     help="single-process form: N models from kx_create_replicas, one host thread each (instead of torchrun)")

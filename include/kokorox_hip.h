@@ -256,6 +256,10 @@ int kx_dispatcher_submit_ex(kx_dispatcher* d, const int64_t* ids, int n_tokens, 
 int kx_dispatcher_stats(kx_dispatcher* d, int64_t* n_requests, int64_t* n_batches, int64_t* max_batch_seen);
 /* batches each model (worker) has run so far: per_model[n_models] */
 int kx_dispatcher_model_batches(kx_dispatcher* d, int64_t* per_model, int n_models);
+/* What went wrong so far: requests that were re-run one by one after their batch failed with an INVALID-class error, and
+ * batches that were run a second time after a DEVICE-class failure (a recurrence hand-off time-out: that model then runs the
+ * one-CU recurrence).  Both stay 0 in a healthy deployment. */
+int kx_dispatcher_failures(kx_dispatcher* d, int64_t* n_replayed, int64_t* n_retried);
 void kx_dispatcher_destroy(kx_dispatcher* d);  /* waits for queued requests; models stay alive */
 
 /* ---- test hooks (used by tests/ only) --------------------------------------------- */

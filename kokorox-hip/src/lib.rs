@@ -95,6 +95,7 @@ extern "C" {
                                err: *mut c_char, err_len: usize) -> c_int;
     fn kx_dispatcher_stats(d: *mut KxDispatcher, n_requests: *mut i64, n_batches: *mut i64,
                            max_batch_seen: *mut i64) -> c_int;
+    fn kx_dispatcher_failures(d: *mut KxDispatcher, n_replayed: *mut i64, n_retried: *mut i64) -> c_int;
     fn kx_dispatcher_model_batches(d: *mut KxDispatcher, per_model: *mut i64, n_models: c_int) -> c_int;
     fn kx_dispatcher_destroy(d: *mut KxDispatcher);
     fn kx_version() -> *const c_char;
@@ -494,6 +495,13 @@ impl HipKokoDispatcher {
         let mut v = vec![0i64; self._models.len()];
         unsafe { kx_dispatcher_model_batches(self.d, v.as_mut_ptr(), v.len() as c_int) };
         v
+    }
+
+    /// (requests replayed one by one after an INVALID-class batch failure, batches retried after a DEVICE-class one).
+    pub fn failures(&self) -> (i64, i64) {
+        let (mut a, mut b) = (0i64, 0i64);
+        unsafe { kx_dispatcher_failures(self.d, &mut a, &mut b) };
+        (a, b)
     }
 
     /// (requests, batches, largest batch) so far.

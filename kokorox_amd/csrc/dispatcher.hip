@@ -164,6 +164,14 @@ int kx_dispatcher_stats(kx_dispatcher* d, int64_t* n_requests, int64_t* n_batche
     return KX_OK;
 }
 
+int kx_dispatcher_failures(kx_dispatcher* d, int64_t* n_replayed, int64_t* n_retried) {
+    if (!d) return KX_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(d->mu);
+    if (n_replayed) *n_replayed = d->n_replayed;
+    if (n_retried) *n_retried = d->n_retried;
+    return KX_OK;
+}
+
 int kx_dispatcher_model_batches(kx_dispatcher* d, int64_t* per_model, int n_models) {
     if (!d || !per_model || n_models < 0) return KX_ERR_INVALID;
     std::lock_guard<std::mutex> lk(d->mu);

@@ -190,6 +190,7 @@ class Model {
     hipEvent_t record_here();               // a pooled event recorded on the current stream (null in the sizing pass)
     void wait_here(hipEvent_t e);           // the current stream waits for it
     struct LaneScope;                       // issue on lane k until the scope ends (model.hip)
+    struct DeviceTurn;                      // one forward at a time per GPU across models (model.hip)
     void sync_lanes();
 
     hipStream_t stream_ = nullptr;

@@ -981,6 +981,41 @@ void Model::profile_read(int64_t* launches, double* ms, double* flops) {
 }
 
 // ---- the forward pass ---------------------------------------------------------------------------
+// ---- one forward at a time per GPU, across the models that live on it -------------------------------------------------
+// Models are meant to be one per GPU, but nothing stops a process from holding several on one device (kx_create_replicas with
+// repeated ids, tests).  Their streams are non-blocking, so their kernels would run side by side - and the two-CU recurrence
+// does not survive that: its 1024-thread, 134 KB-LDS workgroups need a whole CU free at once, the other model's 256-thread conv
+// workgroups refill every slot that frees, and a recurrence's second half can starve until the first half's bounded poll gives
+// up (measured: a 1 - 2 s stall, KX_ERR_DEVICE, fall-back to the one-CU kernel; profiles/r04_serve_models_per_gpu.txt).  So the
+// forwards of the models of one device take turns: a forward's first launch waits (on the GPU, by an event) for the end of
+// the previous forward of ANOTHER model on that device, and the host side queues one forward at a time per device.  With one
+// model per device this is one uncontended mutex and one event record per forward.
+namespace {
+struct DeviceGate {
+    std::mutex mu;
+    hipEvent_t last = nullptr;   // end of the most recent forward queued on this device
+    const void* owner = nullptr; // the model that queued it
+};
+DeviceGate& device_gate(int dev) {
+    static DeviceGate g[KX_MAX_DEVICES];
+    return g[(dev >= 0 && dev < KX_MAX_DEVICES) ? dev : 0];
+}
+}  // namespace
+
+struct Model::DeviceTurn {
+    Model& m;
+    DeviceGate& g;
+    std::unique_lock<std::mutex> lk;
+    explicit DeviceTurn(Model& mm) : m(mm), g(device_gate(mm.device)), lk(g.mu) {
+        if (g.last && g.owner != &m) KX_HIP(hipStreamWaitEvent(m.main_stream_, g.last, 0));
+    }
+    ~DeviceTurn() {  // (also on a failed forward: whatever it queued is what the next model has to wait for)
+        if (!g.last && hipEventCreateWithFlags(&g.last, hipEventDisableTiming) != hipSuccess) g.last = nullptr;
+        if (g.last && hipEventRecord(g.last, m.main_stream_) == hipSuccess) g.owner = &m;
+        else g.owner = nullptr;
+    }
+};
+
 void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* lens_host, int B,
                          const float* d_styles, const float* speeds_host, int n_speed, uint64_t seed, uint32_t flags,
                          float* d_audio, int64_t audio_ld, int32_t* d_frames, int64_t* need_ld) {
@@ -995,6 +1030,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     }
     for (int i = 0; i < n_speed; ++i) KX_REQUIRE(speeds_host[i] > 0.f, "infer: speed must be > 0");
     KX_HIP(hipSetDevice(device));
+    DeviceTurn turn(*this);  // (until this call has queued its last launch)
     B_ = B;
     Tmax_ = Tmax;
     taps_on_ = (flags & 2u) != 0;

@@ -105,6 +105,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                           C.POINTER(i64), cp, sz]),
         "kx_dispatcher_stats": (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
         "kx_dispatcher_model_batches": (i32, [vp, vp, i32]),
+        "kx_dispatcher_failures": (i32, [vp, C.POINTER(i64), C.POINTER(i64)]),
         "kx_dispatcher_destroy": (None, [vp]),
         "kx_debug_tap": (i32, [vp, cp, i32, vp, i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "kx_test_conv1d": (i32, [i32, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp,
@@ -134,7 +135,7 @@ ABI_SYMBOLS = [
     "kx_set_conv_mode", "kx_get_conv_mode", "kx_set_stft_variant", "kx_get_stft_variant",
     "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_profile_aux", "kx_diag_enable", "kx_diag_count", "kx_diag_get", "kx_set_act_prescale", "kx_set_voice_table", "kx_infer_voices",
     "kx_infer_packed", "kx_free_packed", "kx_dispatcher_create", "kx_dispatcher_submit", "kx_dispatcher_submit_ex", "kx_dispatcher_model_batches",
-    "kx_dispatcher_stats", "kx_dispatcher_destroy", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test_attention", "kx_test_conv1d_epilogue", "kx_test_conv1d_full", "kx_test_lstm_fault",
+    "kx_dispatcher_stats", "kx_dispatcher_failures", "kx_dispatcher_destroy", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test_attention", "kx_test_conv1d_epilogue", "kx_test_conv1d_full", "kx_test_lstm_fault",
 ]
 
 
@@ -472,7 +473,10 @@ class Dispatcher:
         self._lib.kx_dispatcher_stats(self._d, C.byref(a), C.byref(b), C.byref(c))
         per = (C.c_int64 * len(self._models))()
         self._lib.kx_dispatcher_model_batches(self._d, per, len(self._models))
-        return {"requests": a.value, "batches": b.value, "max_batch": c.value, "batches_per_model": list(per)}
+        rp, rt = C.c_int64(0), C.c_int64(0)
+        self._lib.kx_dispatcher_failures(self._d, C.byref(rp), C.byref(rt))
+        return {"requests": a.value, "batches": b.value, "max_batch": c.value, "batches_per_model": list(per),
+                "replayed_requests": rp.value, "retried_batches": rt.value}
 
     def close(self):
         if getattr(self, "_d", None):
