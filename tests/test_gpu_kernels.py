@@ -117,9 +117,11 @@ def test_bilstm_more_pairs_than_cus():
 
 
 def test_two_models_run_full_size_forwards_side_by_side(blob_path):
-    """Two models on one GPU, each running batch-32 forwards of 128-phoneme utterances from its own thread: their
-    two-CU LSTM launches contend for CUs (a half may wait for a partner that is queued behind the other model's
-    blocks).  No call may fail with a spurious KX_ERR_DEVICE, and both must equal the result of a quiet run."""
+    """Two models on one GPU, each running batch-32 forwards of 128-phoneme utterances from its own thread.  Left to run side
+    by side their kernels contend for CUs and a half of the two-CU LSTM can starve behind the other model's conv workgroups
+    until its partner's bounded poll gives up (round 4 measured exactly that once the streams became non-blocking: a 1 - 2 s
+    stall, KX_ERR_DEVICE, fall-back to the one-CU kernel whose bits differ).  The forwards of the models of one device
+    therefore take turns (Model::DeviceTurn): no call may fail, and both must equal the result of a quiet run bit for bit."""
     import threading
     from kokorox_amd import hip_koko as hk
     from kokorox_amd import weights as W
