@@ -626,15 +626,18 @@ __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gx_bs,
 // partner never shows up the half raises the model's sticky error word and leaves (an error, never a hang).
 constexpr int LSTMP_REG = 24;           // float4 (4 k) pieces of a thread's 32 held in registers, the rest in LDS
 constexpr int LSTMP_LDS = 32 - LSTMP_REG;
+constexpr int LSTMP_HP = 68;            // pitch of a K quarter of h in LDS (64 values + 4: bank offset between the quarters)
 __global__ __launch_bounds__(1024) void lstm_pair_kernel(const float* gx, long gx_bs, int gx_ld, const float* whhT,
                                                          float* y, long y_bs, int y_ld, LenMap len,
                                                          unsigned long long* xchg, unsigned epoch, unsigned* err,
                                                          int n_pairs, int spin_limit, int drop_half) {
     extern __shared__ __attribute__((aligned(16))) float lstm_smem[];
-    float* hs = lstm_smem;                                   // [256] h of the previous step (both halves)
-    float* gates = hs + 256;                                 // [512] gate pre-activations of this half
+    // h of the previous step (both halves) in four K quarters of 64 with a pitch of 68 floats: the four lanes of a quad read
+    // four different quarters in one instruction, and 272 bytes apart they sit in different banks
+    float* hs = lstm_smem;                                   // [4][LSTMP_HP]
+    float* gates = hs + 4 * LSTMP_HP;                        // [512] gate pre-activations of this half
     int* abort_flag = reinterpret_cast<int*>(gates + 512);   // [4] (one word used): a poll timed out
-    float4* wl = reinterpret_cast<float4*>(gates + 512 + 4); // [LSTMP_LDS][1024] x 4 k: the tail of every thread's 128 k
+    float4* wl = reinterpret_cast<float4*>(gates + 512 + 4); // [LSTMP_LDS][1024] x 4 k: the tail of every thread's 128 weights
     // The two halves of a pair are blocks i and i + 8 of a group of 16: blocks are dealt round-robin over the 8 XCDs, so
     // both halves share one XCD's L2 and the hand-off does not cross the fabric (speed only: nothing depends on it).
     const int hf = (blockIdx.x >> 3) & 1, pair = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);  // pair = b * 2 + dir
@@ -642,50 +645,69 @@ __global__ __launch_bounds__(1024) void lstm_pair_kernel(const float* gx, long g
     if (drop_half && hf == 1) return;                        // (test hook: the partner that never shows up)
     const int b = pair >> 1, dir = pair & 1, tid = threadIdx.x;
     const int L = len_of(len, b);
-    // a wave owns 32 rows; its lower half-wave walks k 0..127 of them, the upper one k 128..255 (combined with one
-    // cross-half-wave add: no LDS round trip, no barrier)
-    const int rr = (tid >> 6) * 32 + (tid & 31), kh = (tid >> 5) & 1;  // local row (gate rr >> 7, unit rr & 127), k half
-    const int row = (rr >> 7) * 256 + hf * 128 + (rr & 127);           // row of W_hh / column of gx
-    // image [k4][row][4 k] (launch_transpose_whh): k4 = kh * 32 + j covers this thread's 128 k
-    const float4* W4 = reinterpret_cast<const float4*>(whhT + (long)dir * 256 * 1024) + (long)kh * 32 * 1024 + row;
-    float4 wreg[LSTMP_REG];
+    // Lane (row pair rp, K quarter kq): TWO rows x 64 k each.  Reading h from LDS is what a step costs most (round 4: with the
+    // partner's values not even waited for, a step took 2.76 of its 2.94 us): every lane used to walk 128 k of ONE row, 32
+    // 16-byte reads of h per step and lane; with two rows per lane a value of h read once feeds two rows: 16 reads.  The four
+    // quarters of a row are the four lanes of a quad and meet in two DPP adds: (q0 + q1) + (q2 + q3).
+    const int kq = tid & 3, rp = tid >> 2;                   // rows 2 rp, 2 rp + 1 of the half's 512 (gate r >> 7, unit r & 127)
+    auto wrow = [&](int rr) { return (rr >> 7) * 256 + hf * 128 + (rr & 127); };  // row of W_hh / column of gx
+    const int rowA = wrow(2 * rp), rowB = wrow(2 * rp + 1);
+    // image [k4][row][4 k] (launch_transpose_whh): k4 = 16 kq + j covers the lane's 64 k
+    const float4* W4 = reinterpret_cast<const float4*>(whhT + (long)dir * 256 * 1024) + (long)kq * 16 * 1024;
+    float4 wreg[LSTMP_REG];  // pieces 2 j + s (s: row A / B), the first 24 in registers, the last 8 (j = 12 .. 15) in LDS
 #pragma unroll
-    for (int j = 0; j < LSTMP_REG; ++j) wreg[j] = W4[(long)j * 1024];
+    for (int i = 0; i < LSTMP_REG; ++i) wreg[i] = W4[(long)(i >> 1) * 1024 + ((i & 1) ? rowB : rowA)];
 #pragma unroll
-    for (int j = 0; j < LSTMP_LDS; ++j) wl[j * 1024 + tid] = W4[(long)(LSTMP_REG + j) * 1024];
-    if (tid < 256) hs[tid] = 0.f;
+    for (int i = 0; i < LSTMP_LDS; ++i) wl[i * 1024 + tid] = W4[(long)((LSTMP_REG + i) >> 1) * 1024 + ((i & 1) ? rowB : rowA)];
+    if (tid < 4 * LSTMP_HP) hs[tid] = 0.f;
     if (tid == 0) *abort_flag = 0;
     float c = 0.f;
     // exchange slots: [pair][parity][half][128] granules
     unsigned long long* mine = xchg + (((long)pair * 2) * 2 + hf) * 128;       // + parity * 256
     unsigned long long* theirs = xchg + (((long)pair * 2) * 2 + (1 - hf)) * 128;
-    const float* gxp = gx + b * gx_bs + dir * 1024 + row;
-    float gxv = (kh == 0 && L > 0) ? gxp[(long)(dir ? L - 1 : 0) * gx_ld] : 0.f;
+    // lanes kq = 0 / 1 of a quad finish row A / B: they carry its input projection
+    const int my_rr = 2 * rp + (kq & 1);
+    const float* gxp = gx + b * gx_bs + dir * 1024 + ((kq & 1) ? rowB : rowA);
+    float gxv = (kq < 2 && L > 0) ? gxp[(long)(dir ? L - 1 : 0) * gx_ld] : 0.f;
+    auto hslot = [](int k) { return (k >> 6) * LSTMP_HP + (k & 63); };  // where h[k] lives
     __syncthreads();
     for (int step = 0; step < L; ++step) {
         const int t = dir ? (L - 1 - step) : step;
-        const float4* h4 = reinterpret_cast<const float4*>(hs) + kh * 32;
-        float acc = 0.f;
+        const float4* h4 = reinterpret_cast<const float4*>(hs + kq * LSTMP_HP);
+        float accA = 0.f, accB = 0.f;
 #pragma unroll
-        for (int j = 0; j < LSTMP_REG; ++j) {
+        for (int j = 0; j < LSTMP_REG / 2; ++j) {
             const float4 hv = h4[j];
-            acc = fmaf(wreg[j].x, hv.x, acc);
-            acc = fmaf(wreg[j].y, hv.y, acc);
-            acc = fmaf(wreg[j].z, hv.z, acc);
-            acc = fmaf(wreg[j].w, hv.w, acc);
+            const float4 wa = wreg[2 * j], wb = wreg[2 * j + 1];
+            accA = fmaf(wa.x, hv.x, accA);
+            accB = fmaf(wb.x, hv.x, accB);
+            accA = fmaf(wa.y, hv.y, accA);
+            accB = fmaf(wb.y, hv.y, accB);
+            accA = fmaf(wa.z, hv.z, accA);
+            accB = fmaf(wb.z, hv.z, accB);
+            accA = fmaf(wa.w, hv.w, accA);
+            accB = fmaf(wb.w, hv.w, accB);
         }
 #pragma unroll
-        for (int j = 0; j < LSTMP_LDS; ++j) {
-            const float4 hv = h4[LSTMP_REG + j];
-            const float4 w = wl[j * 1024 + tid];
-            acc = fmaf(w.x, hv.x, acc);
-            acc = fmaf(w.y, hv.y, acc);
-            acc = fmaf(w.z, hv.z, acc);
-            acc = fmaf(w.w, hv.w, acc);
+        for (int j = 0; j < LSTMP_LDS / 2; ++j) {
+            const float4 hv = h4[LSTMP_REG / 2 + j];
+            const float4 wa = wl[(2 * j) * 1024 + tid], wb = wl[(2 * j + 1) * 1024 + tid];
+            accA = fmaf(wa.x, hv.x, accA);
+            accB = fmaf(wb.x, hv.x, accB);
+            accA = fmaf(wa.y, hv.y, accA);
+            accB = fmaf(wb.y, hv.y, accB);
+            accA = fmaf(wa.z, hv.z, accA);
+            accB = fmaf(wb.z, hv.z, accB);
+            accA = fmaf(wa.w, hv.w, accA);
+            accB = fmaf(wb.w, hv.w, accB);
         }
-        const float other = __shfl_xor(acc, 32);  // the other k half of the same row
-        if (!kh) {
-            gates[rr] = (gxv + acc) + other;
+        // the four K quarters of a row: (q0 + q1) + (q2 + q3) in every lane of the quad
+        accA += __shfl_xor(accA, 1);
+        accB += __shfl_xor(accB, 1);
+        accA += __shfl_xor(accA, 2);
+        accB += __shfl_xor(accB, 2);
+        if (kq < 2) {
+            gates[my_rr] = gxv + ((kq & 1) ? accB : accA);
             // the input projection of the next step (its latency hides behind the rest of this one)
             if (step + 1 < L) gxv = gxp[(long)(dir ? t - 1 : t + 1) * gx_ld];
         }
@@ -703,7 +725,7 @@ __global__ __launch_bounds__(1024) void lstm_pair_kernel(const float* gx, long g
                 const unsigned long long g8 = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(hn);
                 __hip_atomic_store(mine + par * 256 + tid, g8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            hs[hf * 128 + tid] = hn;
+            hs[hslot(hf * 128 + tid)] = hn;
             y[b * y_bs + (long)(dir * 256 + hf * 128 + tid) * y_ld + t] = hn;
         } else if (tid < 256 && step + 1 < L) {
             // threads 128..255 fetch the partner's half: poll each granule until it carries this step's tag
@@ -721,7 +743,7 @@ __global__ __launch_bounds__(1024) void lstm_pair_kernel(const float* gx, long g
                 }
                 if (spins > 64) __builtin_amdgcn_s_sleep(1);  // (a tight poll while the partner is a fraction of a step away)
             }
-            hs[(1 - hf) * 128 + j] = __uint_as_float((unsigned)(g8 & 0xffffffffu));
+            hs[hslot((1 - hf) * 128 + j)] = __uint_as_float((unsigned)(g8 & 0xffffffffu));
         }
         __syncthreads();
         if (*abort_flag) return;  // (workgroup-uniform: written before the barrier above)
@@ -745,7 +767,7 @@ void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, floa
                  LenMap len, int B, unsigned long long* xchg, unsigned* err_word, hipStream_t s, unsigned* epoch_state) {
     static_assert(LSTM_LDS_K % 4 == 0 && LSTM_REG_K % 4 == 0, "whole float4 groups of h");
     if (lstm_use_pair() && xchg && err_word) {
-        const size_t lds = sizeof(float) * (256 + 512 + 4 + (size_t)LSTMP_LDS * 1024 * 4);
+        const size_t lds = sizeof(float) * (4 * LSTMP_HP + 512 + 4 + (size_t)LSTMP_LDS * 1024 * 4);
         static DynLdsLimit pair_limit;  // (per device: each GPU's model launches from its own host thread)
         pair_limit.ensure(reinterpret_cast<const void*>(lstm_pair_kernel), lds);
         // The tag's epoch is 16 bits wide and counted PER exchange buffer (epoch_state; the test hook's one-shot buffer has
