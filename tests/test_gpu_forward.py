@@ -302,6 +302,36 @@ def test_baseline_workload_at_size_batch64_and_batch1(hip_model, oracle):
         hip_model.set_pinned_durations(None)
 
 
+def test_ragged_batch64_at_size_equals_batch1(hip_model, oracle):
+    """The same 64 utterances with their PREDICTED durations (the bench's free-running step: 390 .. 892 frames, 38 507 in all):
+    the conv kernels then take the flat list of live tiles over a really ragged batch at full size.  The shortest, the longest
+    and two others must equal their own B = 1 call (which takes the dense single-utterance grid) bit for bit, the frame counts
+    must be the oracle's durations, and one of them is compared with the oracle, every tap and the waveform."""
+    from oracle import kokoro_ref as R
+    from kokorox_amd import hip_koko as hk
+    from kokorox_amd import weights as W
+    B = 64
+    ids = R.synthetic_inputs(B, 128, seed=0)
+    voices = W.synthetic_voices(4)
+    styles = [voices[b % 4, 128, 0] for b in range(B)]
+    hip_model.set_pinned_durations(None)
+    hip_model.set_utterance_base(0)
+    try:
+        outs = hip_model.infer_batch([list(x) for x in ids], styles, [1.0], seed=2)
+        frames = np.array([o.shape[0] // 600 for o in outs])
+        assert frames.min() < frames.max() and all(np.isfinite(o).all() for o in outs)
+        picks = sorted({int(frames.argmin()), int(frames.argmax()), 17, 40})
+        for b in picks:
+            hip_model.set_utterance_base(b)
+            checked = b == picks[0]
+            one = hip_model.infer([list(ids[b])], [styles[b]], 1.0, seed=2, flags=hk.KX_FLAG_TAPS if checked else 0)
+            np.testing.assert_array_equal(one, outs[b], err_msg=f"utterance {b} ({frames[b]} frames): ragged batch of 64 != batch of 1")
+            if checked:
+                _teacher_forced_oracle_check(hip_model, oracle, ids[b], styles[b], one, b, None)
+    finally:
+        hip_model.set_utterance_base(0)
+
+
 def test_device_entry_point_rejects_bad_ids(hip_model):
     """kx_infer_device takes ids from device memory: the embedding kernels range-check them (clamped gather, sticky
     error word) and the call returns KX_ERR_INVALID instead of reading out of bounds."""
