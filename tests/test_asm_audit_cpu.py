@@ -17,11 +17,32 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
-def _asm(src, tmp_path, *flags):
-    out = tmp_path / (os.path.basename(src) + ".s")
+# every translation unit this file audits, with its extra flags: compiled to assembly side by side on first use (five hipcc runs
+# of 10 - 70 s each; in a row they were most of the CPU suite's time)
+_UNITS = {"conv_f16x3_da.hip": ("-DKX_DA_AUDIT",), "conv_f16x3_da_p1.hip": ("-DKX_DA_AUDIT",), "conv_f16x3_da_w2.hip": ("-DKX_DA_AUDIT",),
+          "conv_f16x3_da_s16.hip": ("-DKX_DA_AUDIT",), "conv_f16x3_dag.hip": ()}
+_ASM_JOBS = {}
+
+
+def _asm_one(src, flags, out_dir):
+    out = os.path.join(out_dir, os.path.basename(src) + ".s")
     subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "--cuda-device-only", "-S", *flags,
-                    os.path.join(ROOT, "kokorox_amd", "csrc", src), "-o", str(out)], check=True, capture_output=True)
-    return out.read_text()
+                    os.path.join(ROOT, "kokorox_amd", "csrc", src), "-o", out], check=True, capture_output=True)
+    return open(out).read()
+
+
+def _asm(src, tmp_path, *flags):
+    """assembly text of `src` (the first call starts all five compilations in parallel; each test waits for its own)"""
+    assert tuple(flags) == _UNITS[src], (src, flags)
+    if not _ASM_JOBS:
+        import tempfile
+        from concurrent.futures import ThreadPoolExecutor
+        out_dir = tempfile.mkdtemp(prefix="kx_asm_audit_")
+        ex = ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1))
+        for u, fl in _UNITS.items():
+            _ASM_JOBS[u] = ex.submit(_asm_one, u, fl, out_dir)
+        ex.shutdown(wait=False)
+    return _ASM_JOBS[src].result()
 
 
 def _kernels(text):
