@@ -629,12 +629,19 @@ struct Importer {
         return unique_tail(name, out);
     }
 
-    // module path from a node name -> full table name, also when the path lacks leading components
+    // module path from a node name -> full table name, also when the path lacks leading components or carries up to two
+    // extra ones (exporters wrap the model: '/kmodel/bert/...', '/model/kmodel/bert/...')
     bool spec_name(const std::string& path, const std::string& leaf, std::string& out) const {
         const std::string full = path.empty() ? leaf : path + "." + leaf;
-        if (in_spec(full)) {
-            out = full;
-            return true;
+        std::string cand = full;
+        for (int strip = 0; strip < 3; ++strip) {
+            if (in_spec(cand)) {
+                out = cand;
+                return true;
+            }
+            const size_t dot = cand.find('.');
+            if (dot == std::string::npos) break;
+            cand = cand.substr(dot + 1);
         }
         return unique_tail(full, out);
     }

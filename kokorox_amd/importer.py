@@ -260,10 +260,16 @@ def onnx_to_state_dict(path: str):
             flat[name] = np.ascontiguousarray(a, dtype=np.float32)
 
     def spec_name(path: str, leaf: str):
-        """module path from a node name -> full state-dict name, also when the path lacks leading components."""
+        """module path from a node name -> full state-dict name, also when the path lacks leading components or carries
+        up to two extra ones (exporters wrap the model: '/kmodel/bert/...', '/model/kmodel/bert/...')."""
         full = f"{path}.{leaf}" if path else leaf
-        if full in spec:
-            return full
+        cand = full
+        for _ in range(3):
+            if cand in spec:
+                return cand
+            if "." not in cand:
+                break
+            cand = cand.split(".", 1)[1]
         tails = [k for k in spec if k.endswith("." + full)]
         return tails[0] if len(tails) == 1 else None
 

@@ -182,7 +182,7 @@ def test_less_common_encodings_agree_between_the_two_readers(synth, tmp_path):
     Gemm (transB = 1, bias as third input), a weight that reaches its MatMul through Cast and through Transpose, a weight in
     a Constant node, ConvInteger with the `_quantized / _scale / _zero_point` naming, DequantizeLinear with block_size,
     bfloat16 and double initialisers, float16 carried in int32_data, a DataParallel-style 'module.' prefix, a wrapped
-    model ('kmodel.' prefix).  The C++ reader and the Python importer must write the same bytes, and the values must be the
+    model ('kmodel.' prefix on an initialiser, '/kmodel/...' and '/model/kmodel/...' on node names).  The C++ reader and the Python importer must write the same bytes, and the values must be the
     expected ones."""
     t = {k: v.copy() for k, v in synth.items()}
     nodes, inits = [], []
@@ -205,13 +205,13 @@ def test_less_common_encodings_agree_between_the_two_readers(synth, tmp_path):
     nodes.append(OX.node_bytes("MatMul", ["x", "c3"], ["mm3"], name="/predictor/duration_proj/linear_layer/MatMul"))
     named("predictor.duration_proj.linear_layer.bias", t["predictor.duration_proj.linear_layer.bias"])
     nodes.append(OX.node_bytes("Add", ["predictor.duration_proj.linear_layer.bias", "mm3"], ["o3"], name="/predictor/duration_proj/linear_layer/Add"))
-    # 3. initialiser stored [out, in] -> Transpose -> MatMul
+    # 3. initialiser stored [out, in] -> Transpose -> MatMul; the node names carry two extra leading components
     k = "bert.encoder.embedding_hidden_mapping_in.weight"
     special[k] = t[k]
     named("onnx::Transpose_4", t[k])
-    nodes.append(OX.node_bytes("Transpose", ["onnx::Transpose_4"], ["t4"], name="/bert/encoder/embedding_hidden_mapping_in/Transpose",
+    nodes.append(OX.node_bytes("Transpose", ["onnx::Transpose_4"], ["t4"], name="/model/kmodel/bert/encoder/embedding_hidden_mapping_in/Transpose",
                                attrs={"perm": [1, 0]}))
-    nodes.append(OX.node_bytes("MatMul", ["x", "t4"], ["mm4"], name="/bert/encoder/embedding_hidden_mapping_in/MatMul"))
+    nodes.append(OX.node_bytes("MatMul", ["x", "t4"], ["mm4"], name="/model/kmodel/bert/encoder/embedding_hidden_mapping_in/MatMul"))
     named("bert.encoder.embedding_hidden_mapping_in.bias", t["bert.encoder.embedding_hidden_mapping_in.bias"])
     nodes.append(OX.node_bytes("Add", ["mm4", "bert.encoder.embedding_hidden_mapping_in.bias"], ["o4"],
                                name="/bert/encoder/embedding_hidden_mapping_in/Add"))
@@ -221,7 +221,7 @@ def test_less_common_encodings_agree_between_the_two_readers(synth, tmp_path):
     cattr = OX._ld(1, b"value") + OX._ld(5, OX.tensor_bytes("", t[k])) + OX._vi(20, 4)
     nodes.append(OX._ld(2, b"const5") + OX._ld(3, b"/decoder/asr_res.0/Constant") + OX._ld(4, b"Constant") + OX._ld(5, cattr))
     named("onnx::Conv_6", t["decoder.asr_res.0.bias"])
-    nodes.append(OX.node_bytes("Conv", ["x", "const5", "onnx::Conv_6"], ["o5"], name="/decoder/asr_res.0/Conv"))
+    nodes.append(OX.node_bytes("Conv", ["x", "const5", "onnx::Conv_6"], ["o5"], name="/kmodel/decoder/asr_res.0/Conv"))
     # 5. ConvInteger, per-tensor scale and zero point
     k = "decoder.generator.noise_convs.1.weight"
     sc = np.float32(np.abs(t[k]).max() / 127.0)
