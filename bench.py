@@ -193,10 +193,12 @@ def serve_leg(models, n_clients=32, per_client=48, max_batch=64, max_wait_us=300
         ids = np.concatenate([[0], r.integers(1, 178, size=k), [0]]).astype(np.int64)
         return ids, rules[int(r.integers(0, len(rules)))], int(r.integers(0, 3)), int(r.integers(1, 2 ** 31))
 
-    # untimed: full-length requests on every model so that the arenas exist at the largest shape
+    # untimed: as many concurrent full-length requests as there will be clients, twice, so that every model's arenas have met
+    # the largest (batch x length) shape of the run (an arena that has to grow in the timed part is a stream sync + hipFree +
+    # hipMalloc of gigabytes: one such regrowth was a 1.3 s latency outlier in a 25 s soak)
     warm = np.array([0] + [5] * 128 + [0], dtype=np.int64)
-    with ThreadPoolExecutor(max_workers=max(2 * len(models), 2)) as ex:
-        list(ex.map(lambda i: d.submit_ex(warm, voices=i % 3, seed=1 + i), range(4 * len(models))))
+    with ThreadPoolExecutor(max_workers=max(n_clients, 2)) as ex:
+        list(ex.map(lambda i: d.submit_ex(warm, voices=i % 3, seed=1 + i), range(2 * n_clients)))
     st0 = d.stats()
     errs = []
 
