@@ -140,6 +140,7 @@ def test_32_clients_mixed_voices_and_formats_over_two_models(blob_path, hip_mode
     with pytest.raises(hk.KokoroxHipError, match="voice id"):
         d.submit_ex(reqs[(0, 0)][0], voices=99, seed=1)
     assert d.stats()["requests"] == st["requests"], "a bad voice id is refused at submit: it must never reach a batch"
+    assert d.stats()["retried_batches"] == 0 and d.stats()["replayed_requests"] == 0, d.stats()  # (kx_dispatcher_failures)
     again = d.submit_ex(reqs[(0, 0)][0], voices=reqs[(0, 0)][3], seed=reqs[(0, 0)][6], fmt=reqs[(0, 0)][5])
     d.close()
     assert not errs, errs
