@@ -246,3 +246,28 @@ def test_tts_chunks_builds_the_reference_calls():
     assert V.tts_chunks(FakeModel(), table, "af", []).shape == (0,)
     with pytest.raises(ValueError):
         V.tts_chunks(FakeModel(), table, "af", [[]])
+
+
+def test_xcd_aware_tile_orders_are_bijections():
+    """The direct-A kernels map a workgroup's dispatch index to a tile so that each of the 8 XCDs gets a contiguous range of
+    tiles (conv_f16x3_da.hip: the dense per-utterance slab form and, for ragged batches, the flat list over all live tiles).
+    Restated here: both maps must hit every tile exactly once, whatever the grid size (a skipped or doubled tile would be a
+    wrong result on the GPU)."""
+    def flat(l, N):
+        q, rem = N >> 3, N & 7
+        cls = l & 7
+        return cls * q + min(cls, rem) + (l >> 3)
+
+    def dense(l, N, z):
+        off = (N * z) & 7
+        cls = (l + off) & 7
+        start = 0
+        for c in range(cls):
+            first = (c - off) & 7
+            start += (N - first + 7) >> 3 if first < N else 0
+        return start + (l >> 3)
+
+    for N in list(range(16, 600)) + [1170, 12672, 16896, 65537]:
+        assert sorted(flat(l, N) for l in range(N)) == list(range(N)), N
+        for z in (0, 1, 5):
+            assert sorted(dense(l, N, z) for l in range(N)) == list(range(N)), (N, z)
