@@ -132,6 +132,15 @@ int kx_sync(kx_model* m);
  * runs).  n = 0 clears it. */
 int kx_set_pinned_durations(kx_model* m, const int32_t* pattern, int n);
 
+/* For servers: one discarded forward of B utterances x n_tokens (incl. the two pads) with every duration pinned to
+ * frames_per_token, so that the model's arenas, its page-locked result buffer and its tile tables already have the largest
+ * (batch x length) shape the deployment expects when the first request arrives.  Without it the arenas grow on demand - a
+ * stream sync + hipFree + hipMalloc of gigabytes, measured as a 1.3 s latency outlier the first time a larger batch shape
+ * arrives.  No reference counterpart (ONNX Runtime allocates per run).  A pinned pattern set before stays in force. */
+int kx_warmup(kx_model* m, int B, int n_tokens, int frames_per_token);
+/* Capacities in bytes of the three device arenas (token axis, frame axis, I/O): they change only when a larger shape arrives. */
+int kx_arena_bytes(kx_model* m, int64_t* out3);
+
 /* Contraction arithmetic of the conv/linear kernel: 0 = f32 MFMA (v_mfma_f32_32x32x2_f32, exact f32
  * products), 1 = f16x3 split MFMA (three v_mfma_f32_32x32x16_f16 per K-step on hi/lo halves, ~22
  * significant bits per product, f32 accumulation).  Default 1; env KOKOROX_CONV=f32 selects 0 at create.

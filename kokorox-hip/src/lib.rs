@@ -60,6 +60,8 @@ extern "C" {
                        d_styles: *const f32, speeds_host: *const f32, n_speed: c_int, seed: u64, flags: u32,
                        d_audio: *mut f32, audio_ld: i64, d_frames: *mut i32, need_ld: *mut i64) -> c_int;
     fn kx_sync(m: *mut KxModel) -> c_int;
+    fn kx_warmup(m: *mut KxModel, b: c_int, n_tokens: c_int, frames_per_token: c_int) -> c_int;
+    fn kx_arena_bytes(m: *mut KxModel, out3: *mut i64) -> c_int;
     fn kx_set_pinned_durations(m: *mut KxModel, pattern: *const i32, n: c_int) -> c_int;
     fn kx_set_conv_mode(m: *mut KxModel, mode: c_int) -> c_int;
     fn kx_get_conv_mode(m: *mut KxModel) -> c_int;
@@ -324,6 +326,17 @@ impl HipKoko {
     }
     pub fn set_pinned_durations(&self, pattern: &[i32]) -> Result<(), Box<dyn Error>> {
         self.check(unsafe { kx_set_pinned_durations(self.h, pattern.as_ptr(), pattern.len() as c_int) })
+    }
+    /// For servers: one discarded forward at the largest (batch x length) shape the deployment expects, so that the arenas and
+    /// the page-locked result buffer exist before the first request (an arena that grows under load is a second-long outlier).
+    pub fn warmup(&self, batch: i32, n_tokens: i32, frames_per_token: i32) -> Result<(), Box<dyn Error>> {
+        self.check(unsafe { kx_warmup(self.h, batch, n_tokens, frames_per_token) })
+    }
+    /// Capacities in bytes of the token-axis, frame-axis and I/O arenas.
+    pub fn arena_bytes(&self) -> Result<[i64; 3], Box<dyn Error>> {
+        let mut v = [0i64; 3];
+        self.check(unsafe { kx_arena_bytes(self.h, v.as_mut_ptr()) })?;
+        Ok(v)
     }
     pub fn set_conv_mode(&self, mode: i32) -> Result<(), Box<dyn Error>> {
         self.check(unsafe { kx_set_conv_mode(self.h, mode) })

@@ -245,6 +245,15 @@ int kx_set_pinned_durations(kx_model* m, const int32_t* pattern, int n) {
     return guarded(m, [&](Model& M) { M.set_pinned(pattern, n); });
 }
 
+int kx_warmup(kx_model* m, int B, int n_tokens, int frames_per_token) {
+    return guarded(m, [&](Model& M) { M.warmup(B, n_tokens, frames_per_token); });
+}
+
+int kx_arena_bytes(kx_model* m, int64_t* out3) {
+    if (!out3) return KX_ERR_INVALID;
+    return guarded(m, [&](Model& M) { M.arena_bytes(out3); });
+}
+
 int kx_set_conv_mode(kx_model* m, int mode) {
     return guarded(m, [&](Model& M) {
         KX_REQUIRE(mode == kx::CONV_F32 || mode == kx::CONV_F16X3 || mode == kx::CONV_F16,

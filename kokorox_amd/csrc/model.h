@@ -129,6 +129,10 @@ class Model {
     void sync();
     void order_after_null_stream();
     void set_pinned(const int32_t* pattern, int n);
+    // one forward of B utterances x n_tokens with every duration pinned to frames_per_token, output discarded: sizes the arenas,
+    // the pooled page-locked buffer and the flat tile tables for that shape before the first real request
+    void warmup(int B, int n_tokens, int frames_per_token);
+    void arena_bytes(int64_t out[3]) const { out[0] = (int64_t)arenaT_.cap; out[1] = (int64_t)arenaF_.cap; out[2] = (int64_t)arenaIO_.cap; }
     void profile_enable(bool on);
     void profile_read(int64_t* launches, double* ms, double* flops);
     struct ProfRec { int rows, Cin, K, dil, stride, store; double cols, flops; float ms; double bytes; };

@@ -892,6 +892,41 @@ void Model::set_pinned(const int32_t* pattern, int n) {
     n_pinned_ = n;
 }
 
+void Model::warmup(int B, int n_tokens, int frames_per_token) {
+    KX_REQUIRE(B >= 1 && B <= 4096 && n_tokens >= 2 && n_tokens <= 512 && frames_per_token >= 1 && frames_per_token <= 50,
+               "warmup: 1..4096 utterances of 2..512 tokens at 1..50 frames per token");
+    // (the caller's pinned pattern, if any, is put back afterwards)
+    std::vector<int32_t> saved((size_t)n_pinned_);
+    if (n_pinned_) {
+        KX_HIP(hipSetDevice(device));
+        KX_HIP(hipStreamSynchronize(stream_));
+        KX_HIP(hipMemcpy(saved.data(), d_pinned_, saved.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    const int32_t fpt = frames_per_token;
+    set_pinned(&fpt, 1);
+    struct Restore {
+        Model& m;
+        std::vector<int32_t>& s;
+        ~Restore() {
+            try {
+                m.set_pinned(s.empty() ? nullptr : s.data(), (int)s.size());
+            } catch (...) {
+            }
+        }
+    } restore{*this, saved};
+    std::vector<int64_t> ids((size_t)B * n_tokens, 1);
+    for (int b = 0; b < B; ++b) ids[(size_t)b * n_tokens] = ids[(size_t)b * n_tokens + n_tokens - 1] = 0;  // the two pads
+    std::vector<int32_t> lens((size_t)B, n_tokens);
+    std::vector<float> styles((size_t)B * 256, 0.f);
+    const float speed = 1.f;
+    HostCall hc;
+    hc.styles = styles.data();
+    void* out = nullptr;
+    std::vector<int64_t> bytes((size_t)B), samples((size_t)B);
+    infer_host_ex(ids.data(), n_tokens, lens.data(), B, &speed, 1, 0, 1u /* noise off */, hc, &out, bytes.data(), samples.data());
+    host_out_free(out);
+}
+
 void Model::diag_enable(bool on) {
     sync();
     diag_on_ = on;

@@ -71,6 +71,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_init": (i32, [i32, cp, sz]),
         "kx_create": (vp, [cp, i32, cp, sz]),
         "kx_import_onnx": (i32, [cp, cp, cp, sz]),
+        "kx_warmup": (i32, [vp, i32, i32, i32]),
+        "kx_arena_bytes": (i32, [vp, C.POINTER(i64)]),
         "kx_create_from_device_blob": (vp, [vp, sz, i32, cp, sz]),
         "kx_destroy": (None, [vp]),
         "kx_last_error": (cp, [vp]),
@@ -131,7 +133,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 ABI_SYMBOLS = [
     "kx_version", "kx_init", "kx_create", "kx_import_onnx", "kx_create_from_device_blob", "kx_create_replicas", "kx_destroy",
     "kx_last_error", "kx_last_error_copy", "kx_infer",
-    "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_set_utterance_base", "kx_set_lanes",
+    "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_warmup", "kx_arena_bytes", "kx_set_utterance_base", "kx_set_lanes",
     "kx_set_conv_mode", "kx_get_conv_mode", "kx_set_stft_variant", "kx_get_stft_variant",
     "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_profile_aux", "kx_diag_enable", "kx_diag_count", "kx_diag_get", "kx_set_act_prescale", "kx_set_voice_table", "kx_infer_voices",
     "kx_infer_packed", "kx_free_packed", "kx_dispatcher_create", "kx_dispatcher_submit", "kx_dispatcher_submit_ex", "kx_dispatcher_model_batches",
@@ -317,6 +319,15 @@ class HipKoko:
             return
         p = np.ascontiguousarray(pattern, dtype=np.int32)
         self._check(self._lib.kx_set_pinned_durations(self._h, _ptr(p), p.shape[0]))
+
+    def warmup(self, B: int, n_tokens: int, frames_per_token: int = 8):
+        """Size the arenas / result buffer for B utterances x n_tokens at frames_per_token frames per token (kx_warmup)."""
+        self._check(self._lib.kx_warmup(self._h, B, n_tokens, frames_per_token))
+
+    def arena_bytes(self):
+        out = (C.c_int64 * 3)()
+        self._check(self._lib.kx_arena_bytes(self._h, out))
+        return list(out)
 
     def set_conv_mode(self, mode: int):
         """0 = f32 MFMA, 1 = f16x3 split MFMA (default), 4 = f16 single product (opt-in reduced precision)."""

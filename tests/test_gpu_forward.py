@@ -332,6 +332,37 @@ def test_ragged_batch64_at_size_equals_batch1(hip_model, oracle):
         hip_model.set_utterance_base(0)
 
 
+def test_warmup_sizes_the_arenas_ahead_of_the_first_request(blob_path):
+    """kx_warmup (for servers): after it, a batch inside the warmed shape must not grow any arena (a regrowth under load is a
+    stream sync + hipFree + hipMalloc of gigabytes: the 1.3 s outlier of profiles/r04_serve_models_per_gpu.txt), a pinned
+    pattern set before must survive it, and results must not depend on it."""
+    from kokorox_amd import hip_koko as hk
+    ids, styles = _inputs([40, 25, 33, 12, 40, 9, 31, 38], seed0=123)
+    m = hk.HipKoko.new(blob_path)
+    try:
+        assert m.arena_bytes() == [0, 0, 0]
+        m.warmup(8, 42, 8)
+        cap = m.arena_bytes()
+        assert all(c > 0 for c in cap)
+        out = m.infer_batch([list(x) for x in ids], [list(s) for s in styles], [1.0], seed=3)
+        assert m.arena_bytes() == cap, "a batch inside the warmed shape grew an arena"
+        m2 = hk.HipKoko.new(blob_path)
+        try:
+            ref = m2.infer_batch([list(x) for x in ids], [list(s) for s in styles], [1.0], seed=3)
+        finally:
+            m2.close()
+        for a, b in zip(out, ref):
+            np.testing.assert_array_equal(a, b)
+        m.set_pinned_durations([2, 3])
+        m.warmup(2, 20, 5)
+        one = m.infer([list(ids[3])], [list(styles[3])], 1.0, seed=3)
+        assert one.shape[0] == 600 * sum([2, 3][i % 2] for i in range(len(ids[3])))
+        with pytest.raises(hk.KokoroxHipError, match="warmup"):
+            m.warmup(0, 20, 5)
+    finally:
+        m.close()
+
+
 def test_device_entry_point_rejects_bad_ids(hip_model):
     """kx_infer_device takes ids from device memory: the embedding kernels range-check them (clamped gather, sticky
     error word) and the call returns KX_ERR_INVALID instead of reading out of bounds."""
