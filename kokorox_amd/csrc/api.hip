@@ -397,7 +397,11 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
         KX_HIP(hipSetDevice(device_id));
         DevMem dm;
         std::vector<int> lens(B, 1);
+        // bit 8 of the mode: stage the input through a pre-split image (conv_f16x3_pre.hip), whatever the layer's row count
+        const bool pre = (mode & 0x100) != 0;
+        mode &= 0xff;
         KX_REQUIRE(mode >= kx::CONV_F32 && mode <= kx::CONV_F16X3_DA, "test_conv1d: mode must be 0, 1, 2 or 3");
+        KX_REQUIRE(!pre || mode == kx::CONV_F16X3 || mode == kx::CONV_F16X3_DA, "test_conv1d: pre-split images exist for the direct-A kernels only");
         kx::ConvArgs a{};
         a.ws_force = mode == kx::CONV_F16X3_LDS ? 1 : (mode == kx::CONV_F16X3_DA ? 2 : 0);
         // row strides: the caller's dense rows, or (pad_ld) the model's: a multiple of 32 floats, input padding poisoned
@@ -547,6 +551,17 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
                     a.flat_tiles_host = total;
                     a.flat_bn_host = fbn;
                 }
+            }
+            if (pre) {
+                KX_REQUIRE(BM == 128 && a.K >= 2 && a.act != kx::ACT_SNAKE && kx::conv16_da_eligible(BM, a.K, a.dil, a.stride, 0),
+                           "test_conv1d: this layer has no pre-split form");
+                const long img_bs = (long)kx::conv16_pre_image_bytes(Cin, x_ld);
+                unsigned char* img = dm.get<unsigned char>((size_t)B * img_bs);
+                KX_HIP(hipMemset(img, 0xff, (size_t)B * img_bs));  // (NaN halves wherever the pass does not write)
+                kx::launch_split_image(a, B, L, img, img_bs, nullptr);
+                a.x16 = img;
+                a.x16_bs = img_bs;
+                a.x16_ld = x_ld;
             }
             kx::launch_conv1d_f16x3(a, BM, B, max_cols, nullptr);
         } else {

@@ -53,7 +53,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-#if !defined(KX_DA_P1) && !defined(KX_DA_W2) && !defined(KX_DA_S16)
+#if !defined(KX_DA_P1) && !defined(KX_DA_W2) && !defined(KX_DA_S16) && !defined(KX_DA_PRE)
 bool conv16_da_eligible(int BM, int K, int dil, int stride, int merged) {
     return BM == 128 && stride == 1 && !merged && (K - 1) * dil + 256 <= 384;
 }
@@ -68,8 +68,14 @@ bool conv16_use_da(int BM, int K, int dil, int stride, int merged) {
 // rounded to f16, f32 accumulation); the low halves are neither loaded, nor computed, nor read.
 // W2: the unrolled main loop with the four waves as 2 x 2 (64 rows x 128 columns each), see "W2 form" below.
 // S16: the unrolled main loop on v_mfma_f32_16x16x32_f16 (K = 32 = the 16 channels of a chunk x TWO taps), see "S16 form" below.
-template <int ACT, int KT, int NTT, bool P1, bool W2 = false, bool S16 = false>
+// PRE: the input arrives as a pre-split image (ConvArgs::x16, written once per tensor by split_image_kernel, conv_f16x3_pre.hip:
+// AdaIN affine + activation + f16 hi / lo split already applied, in the very layout of the LDS image), so staging a chunk is
+// NLD 16-byte loads and NLD 16-byte LDS writes per lane and the transform is gone from this kernel.  For layers whose input
+// window is staged by many row tiles (the 1024-row decoder convs: 8, the polyphase upsamplers: 20 / 6), each of which would
+// otherwise repeat the transform of the same window (profiles/r05_pmc_sq_*.txt: 9 - 14 vector instructions per MFMA there).
+template <int ACT, int KT, int NTT, bool P1, bool W2 = false, bool S16 = false, bool PRE = false>
 __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_da_kernel(const ConvArgs a) {
+    static_assert(!PRE || (!P1 && !S16 && ACT == ACT_NONE), "PRE: the activation lives in the image; f16x3 forms on 32x32x16 only");
     static_assert(!W2 || (KT >= 3 && (KT & 1) && NTT == 8), "W2: odd compile-time tap counts on the 256-column tile");
     static_assert(!S16 || (KT >= 3 && (KT & 1) && !P1 && !W2), "S16: odd compile-time tap counts, three MFMAs per product, 4 x 1 waves");
     static_assert(NTT == 8 || NTT == 4 || (NTT == 6 && S16), "tile widths: 256, 128, and 192 columns in the S16 form");
@@ -198,6 +204,27 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
         pi = pi < 0 ? 0 : (pi >= Lsrc ? Lsrc - 1 : pi);
         xoff[j] = pi;
     }
+    // PRE: lane t moves the uint4 t + 256 i (i < NLD) of a chunk's [hi|lo][octet][XWp] image from global memory to LDS: plane
+    // = index / XWp, window column = index % XWp; the byte offset inside a chunk of the global image and the in-range flag do not
+    // depend on the chunk (columns outside [0, Lin) are zero padding: loaded from a clamped address, written as zeros)
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    constexpr int NLD = PRE ? (4 * XWp) / 256 : 1;
+    static_assert(!PRE || (4 * XWp) % 256 == 0, "PRE: whole rounds of 256 lanes");
+    u32x4 rawq[NLD];
+    unsigned qoff[NLD];
+    unsigned okq = 0;
+    const buf_rsrc xq = make_buf(PRE ? reinterpret_cast<const char*>(a.x16) + (long)b * a.x16_bs : reinterpret_cast<const char*>(a.x));
+    const unsigned chunk_bytes = PRE ? 64u * (unsigned)a.x16_ld : 0u;  // four planes of x16_ld columns x 16 B
+    if constexpr (PRE) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + 256 * i, plane = idx / XWp, u = idx - plane * XWp;
+            const int p = p0 + u;
+            okq |= (p >= 0 && p < Lin) ? (1u << i) : 0u;
+            const int pc = p < 0 ? 0 : (p >= Lin ? Lin - 1 : p);
+            qoff[i] = 16u * (unsigned)(plane * a.x16_ld + pc);
+        }
+    }
     const int cmax_in = a.Cin - 1;
     // (the three InstanceNorm parameter loads are UNCONDITIONAL -- without a norm they read the first input row and are
     // discarded -- so that a prefetch batch is the same number of vector loads whatever the launch: wait_A counts them, and
@@ -219,6 +246,12 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
                                                           // division here would wait for the load on the spot)
     };
     auto load_raw = [&](int ch) __attribute__((always_inline)) {
+        if constexpr (PRE) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)
+                rawq[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xq, qoff[i], (unsigned)ch * chunk_bytes, 0));
+            return;
+        }
         load_params(ch, praw);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -289,7 +322,18 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
         Xw2[((0 * 2 + g) * XWp + u) * 2 + jb] = make_uint2(hp[0], hp[1]);
         if constexpr (!P1) Xw2[((1 * 2 + g) * XWp + u) * 2 + jb] = make_uint2(lp[0], lp[1]);
     };
+    // PRE: unit i of a chunk's staging = one 16-byte LDS write (conflict-free: consecutive lanes, consecutive 16 B)
+    auto pre_unit = [&](const int i, uint4* Xb) __attribute__((always_inline)) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        const u32x4 v = ((okq >> i) & 1u) ? rawq[i] : z;
+        Xb[tid + 256 * i] = __builtin_bit_cast(uint4, v);
+    };
     auto stage_from_raw = [&](uint4* Xb, int ch) __attribute__((always_inline)) {
+        if constexpr (PRE) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) pre_unit(i, Xb);
+            return;
+        }
         Oct o;
         unpack_params(praw, o);
 #pragma unroll
@@ -387,7 +431,6 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
     // operations issued after slot i's refill (2 per refill of another slot, raw_ops per input prefetch batch); the
     // compiler's own waits for its own loads stay safe, they can only over-wait when these loads sit among theirs.
     const uint4* wlane = reinterpret_cast<const uint4*>(a.w16) + (long)ct * n_steps * tap_units + h * BM + wave * 32 + r;
-    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
     auto load_A = [&](int s, u32x4& a_hi, u32x4& a_lo) __attribute__((always_inline)) {
         const int sc = s < n_steps ? s : n_steps - 1;  // (only the three loads of the prologue can point past the end)
         const uint4* p = wlane + (long)sc * tap_units;
@@ -461,7 +504,9 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
     };
     // vector loads of one load_raw(): exact counting is worth 2 % of the step against counting the asm loads only (always
     // a safe under-estimate: 123.8 vs 126.2 ms)
-    constexpr int raw_ops = HU + 3 + (ACT == ACT_SNAKE ? 1 : 0);
+    constexpr int raw_ops = PRE ? NLD : HU + 3 + (ACT == ACT_SNAKE ? 1 : 0);
+    constexpr int HUX = PRE ? NLD : HU;   // units of a chunk's staging dealt out between the MFMAs of the unrolled forms
+    constexpr int UVI = PRE ? 5 : 27;     // vector instructions of one unit (what the scheduling pipelines are sized for)
     // Three-deep A ring with STATIC slots: step s uses slot s % 3 and refills it for step s + 3 as soon as its MFMAs are
     // issued, so a fragment is requested two whole steps before its use and nothing ever moves between registers.  The
     // (chunk, tap) walk is flattened and unrolled by three for that.
@@ -729,20 +774,24 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
                 acc[0][NW + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, fh[e], acc[0][NW + n], 0, 0, 0);
                 // half-units [h0, h1) of the next chunk's transform ride on this tile (in the last chunk: stale registers into an
                 // image nobody reads)
-                constexpr int h0 = i > I0 ? ((i - I0) * HU) / (TILES - I0) : 0;
-                constexpr int h1 = i + 1 > I0 ? ((i + 1 - I0) * HU) / (TILES - I0) : 0;
+                constexpr int h0 = i > I0 ? ((i - I0) * HUX) / (TILES - I0) : 0;
+                constexpr int h1 = i + 1 > I0 ? ((i + 1 - I0) * HUX) / (TILES - I0) : 0;
                 static_assert(h1 - h0 <= 4, "at most four half-units per tile");
                 static_for<h0, h1>([&](auto hc) __attribute__((always_inline)) {
                     constexpr int hh = decltype(hc)::value;
-                    xform_a(hh / 2, hh & 1, ch + 1);
-                    xform_b();
-                    xform_c(hh / 2, hh & 1, Xs + (cur ^ 1) * XBUF, ch + 1);
+                    if constexpr (PRE) {
+                        pre_unit(hh, Xs + (cur ^ 1) * XBUF);
+                    } else {
+                        xform_a(hh / 2, hh & 1, ch + 1);
+                        xform_b();
+                        xform_c(hh / 2, hh & 1, Xs + (cur ^ 1) * XBUF, ch + 1);
+                    }
                 });
                 if constexpr (i % G == G - 1) {  // the pipeline of the region: its half-units spread over its MFMAs
                     constexpr int ig = i - (G - 1);
-                    constexpr int hg0 = ig > I0 ? ((ig - I0) * HU) / (TILES - I0) : 0;
+                    constexpr int hg0 = ig > I0 ? ((ig - I0) * HUX) / (TILES - I0) : 0;
                     constexpr int nh = h1 - hg0;
-                    constexpr int per = nh > 0 ? (nh * 27 + MPT * G - 1) / (MPT * G) : 0;
+                    constexpr int per = nh > 0 ? (nh * UVI + MPT * G - 1) / (MPT * G) : 0;
 #pragma unroll
                     for (int tg = 0; tg < G; ++tg) {
                         if (tg > 0) __builtin_amdgcn_sched_group_barrier(0x100, P1 ? 1 : 2, 0);
@@ -845,8 +894,8 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
                 acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fh[e], acc[0][n], 0, 0, 0);
                 // half-units [h0, h1) of the next chunk's transform ride on this tile (in the last chunk they run on
                 // stale registers into the image nobody reads: cheaper than a second version of the loop)
-                constexpr int h0 = i > I0 ? ((i - I0) * HU) / (TILES - I0) : 0;
-                constexpr int h1 = i + 1 > I0 ? ((i + 1 - I0) * HU) / (TILES - I0) : 0;
+                constexpr int h0 = i > I0 ? ((i - I0) * HUX) / (TILES - I0) : 0;
+                constexpr int h1 = i + 1 > I0 ? ((i + 1 - I0) * HUX) / (TILES - I0) : 0;
                 // (no run-time condition around them: a branch would put them in a block of their own, behind the MFMAs
                 // instead of between them)
 #ifdef KX_DA_NO_XFORM  // (diagnostic build: the transform's vector work and LDS writes dropped, image stale: compare CYCLES, not time)
@@ -860,6 +909,10 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
                 if constexpr (h1 > h0) keep_elem(h0);
                 if constexpr (h1 > h0 + 1) keep_elem(h0 + 1);
 #endif
+                if constexpr (PRE) {
+                    if constexpr (h1 > h0) pre_unit(h0, Xs + (cur ^ 1) * XBUF);
+                    if constexpr (h1 > h0 + 1) pre_unit(h0 + 1, Xs + (cur ^ 1) * XBUF);
+                } else {
                 if constexpr (do_xform && h1 > h0) {
                     xform_a(h0 / 2, h0 & 1, ch + 1);
                     xform_b();
@@ -870,13 +923,14 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
                     xform_b();
                     xform_c((h0 + 1) / 2, (h0 + 1) & 1, Xs + (cur ^ 1) * XBUF, ch + 1);
                 }
+                }
                 static_assert(h1 - h0 <= 2, "at most two half-units per tile");
                 if constexpr (G > 1) {
                     if constexpr (i % G == G - 1) {  // the pipeline of the whole group, written at its end
                         constexpr int ig = i - (G - 1);
-                        constexpr int hg0 = ig > I0 ? ((ig - I0) * HU) / (TILES - I0) : 0;
+                        constexpr int hg0 = ig > I0 ? ((ig - I0) * HUX) / (TILES - I0) : 0;
                         constexpr int nh = h1 - hg0;                                   // half-units in the group
-                        constexpr int per = nh > 0 ? (nh * 27 + 3 * G - 1) / (3 * G) : 0;  // vector instructions per MFMA
+                        constexpr int per = nh > 0 ? (nh * UVI + 3 * G - 1) / (3 * G) : 0;  // vector instructions per MFMA
 #pragma unroll
                         for (int tg = 0; tg < G; ++tg) {
                             // (the fragment reads of the later tiles of the group stay ahead of their tile's MFMAs; opening EVERY tile
@@ -990,7 +1044,7 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
             tt = 0;
             ++ch;
             if (ch < n_chunks) {
-                if (a.dbg & 4096) {  // (bit 4096: the loads are waited for and dropped, no transform, no LDS writes)
+                if (!PRE && (a.dbg & 4096)) {  // (bit 4096: the loads are waited for and dropped, no transform, no LDS writes)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -1084,9 +1138,9 @@ constexpr bool DA_S16 = true;
 constexpr bool DA_S16 = false;
 #endif
 
-template <int ACT, int KT, int NTT>
+template <int ACT, int KT, int NTT, bool W2X = DA_W2, bool PREX = false>
 static void launch_da_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
-    auto kern = conv1d_f16x3_da_kernel<ACT, KT, NTT, DA_P1, DA_W2, DA_S16>;
+    auto kern = conv1d_f16x3_da_kernel<ACT, KT, NTT, DA_P1, W2X, DA_S16, PREX>;
     constexpr int BN = 32 * NTT;
     // two input buffers (48 / 32 KiB), and never less than the statistics scratch of the epilogue (4 waves x 8.25 KiB)
     constexpr size_t lds_x = 16 * (size_t)2 * 4 * (BN + 128), lds_scr = 4 * 32 * 33 * sizeof(float2);
@@ -1103,7 +1157,25 @@ static void launch_da_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s
     KX_HIP(hipGetLastError());
 }
 
-#ifdef KX_DA_S16
+#ifdef KX_DA_PRE
+// The PRE forms (conv_f16x3_da_pre.hip defines KX_DA_PRE and includes this file): the input is a pre-split image (a.x16).  Which
+// launches get one is decided from the layer's shape alone (conv16_pre_shape, conv_f16x3_pre.hip), never from the batch.
+void launch_conv1d_f16x3_da_pre(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn) {
+    KX_REQUIRE(a.x16 != nullptr && a.x16_ld > 0 && !a.in_up2 && !a.prec1 && a.stride == 1 && a.merge_T == 0,
+               "conv1d f16x3 da pre: launch not eligible");
+    KX_REQUIRE(bn == 256 || bn == 128, "conv1d f16x3 da pre: tile of 256 or 128 columns");
+    // the chunk term of the image offsets is a 32-bit scalar: n_chunks x four planes x x16_ld x 16 B per utterance
+    KX_REQUIRE((long)a.n_chunks16 * 64 * a.x16_ld < (1L << 31), "conv1d f16x3 da pre: image of one utterance beyond 2 GiB");
+    const bool w64 = a.K == 3 && (a.K - 1) * a.dil <= 64;  // the unrolled 3-tap forms (W2 on the 256-column tile); else run-time taps
+    if (bn == 256) {
+        if (w64) launch_da_inst<ACT_NONE, 3, 8, true, true>(a, B, max_cols, s);
+        else launch_da_inst<ACT_NONE, 0, 8, false, true>(a, B, max_cols, s);
+    } else {
+        if (w64) launch_da_inst<ACT_NONE, 3, 4, false, true>(a, B, max_cols, s);
+        else launch_da_inst<ACT_NONE, 0, 4, false, true>(a, B, max_cols, s);
+    }
+}
+#elif defined(KX_DA_S16)
 // The S16 forms (conv_f16x3_da_s16.hip defines KX_DA_S16 and includes this file).
 // Shapes the S16 form takes (and conv16_pick_tile gives 64-column statistics slots): snake resblock convs with 11 taps and an even
 // number of 16-channel chunks, and (round 4) the un-dilated 7-tap ones.  KX_DA_S16=0 switches the form off, 2 keeps it to 11 taps.
@@ -1184,7 +1256,7 @@ static void launch_da_ntt(const ConvArgs& a, int B, int max_cols, hipStream_t s)
 
 #endif  // KX_DA_W2
 
-#if defined(KX_DA_W2) || defined(KX_DA_S16)
+#if defined(KX_DA_W2) || defined(KX_DA_S16) || defined(KX_DA_PRE)
 #elif defined(KX_DA_P1)
 // bn: 256 or 128, as launch_conv1d_f16x3_da (which forwards here when a.prec1 is set)
 void launch_conv1d_f16x3_da_p1(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn) {
@@ -1195,6 +1267,7 @@ void launch_conv1d_f16x3_da_p1(const ConvArgs& a, int B, int max_cols, hipStream
 }
 #else
 void launch_conv1d_f16x3_da_p1(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn);  // conv_f16x3_da_p1.hip
+void launch_conv1d_f16x3_da_pre(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn);  // conv_f16x3_da_pre.hip
 
 // bn: 256 (chip-filling launches) or 128 (small grids); the statistics slots are 128 columns wide either way
 void launch_conv1d_f16x3_da(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn) {
@@ -1203,6 +1276,11 @@ void launch_conv1d_f16x3_da(const ConvArgs& a, int B, int max_cols, hipStream_t 
     KX_REQUIRE(a.epi != EPI_GELU_NEW, "conv1d f16x3 da: no gelu epilogue");
     KX_REQUIRE(bn == 256 || bn == 128 || bn == 192, "conv1d f16x3 da: tile of 256, 192 or 128 columns");
     if (max_cols <= 0) return;
+    if (a.x16) {  // pre-split input image (conv_f16x3_pre.hip decides which layers get one)
+        KX_REQUIRE(bn != 192, "conv1d f16x3 da: no pre-split form of the 192-column tile");
+        launch_conv1d_f16x3_da_pre(a, B, max_cols, s, bn);
+        return;
+    }
     // 7 / 11-tap snake convs: the 16x16x32 form on its 192- or 128-column tile (conv16_pick_tile chose bn and the 64-column
     // statistics slots for it by the same predicate)
     if (conv16_da_s16_shape(128, a.K, a.dil, a.stride, a.act, a.n_chunks16, a.merge_T > 0, a.prec1 != 0)) {

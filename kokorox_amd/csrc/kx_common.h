@@ -129,7 +129,19 @@ struct ConvArgs {
     int flat_ny;     // row tiles (the fastest index of the list)
     int flat_B;
     int flat_tiles_host, flat_bn_host;  // host side only: tile_prefix[B] as the host counted it, and the tile width it assumed
+    // Pre-split input image (direct-A convs whose window is staged by many row tiles; conv_f16x3_pre.hip): the input after
+    // its AdaIN affine, activation, pre-scale and f16 hi / lo split, per utterance [chunk of 16 channels][hi|lo][octet][x16_ld
+    // columns][8 halves] = the kernels' LDS image; x16_bs bytes per utterance.  null = the kernel transforms a.x itself.
+    const void* x16;
+    long x16_bs;
+    int x16_ld;
 };
+
+// pre-split images (conv_f16x3_pre.hip)
+bool conv16_pre_shape(int BM, int rows, int K, int dil, int stride, int act, int in_up2);  // which layers get one: by shape alone
+size_t conv16_pre_image_bytes(int Cin, int x_ld);  // per utterance
+// writes the image of a.x (a's norm parameters, activation, slope, pre-scale) for B utterances of at most Lmax columns
+void launch_split_image(const ConvArgs& a, int B, int Lmax, void* img, long img_bs, hipStream_t s);
 
 // tile_prefix of a LenMap for `bn`-column tiles (+ `extra` columns per utterance: the polyphase convs' L + 1), on the device
 void launch_tile_prefix(LenMap len, int extra, int bn, int B, int* out, hipStream_t s);

@@ -219,6 +219,7 @@ class Model {
     std::atomic<int> n_voices_{0};
     int* d_pinned_ = nullptr;
     Arena* stats_arena_ = nullptr;  // where stats() keeps the raw sums of tensors it had to read (frame-axis arena)
+    Arena* img_arena_ = nullptr;    // where conv() puts pre-split input images; non-null only while the back half is issued
     int n_pinned_ = 0;
 
     // per-call state

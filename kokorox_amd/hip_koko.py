@@ -525,8 +525,9 @@ STFT_ONNX, STFT_TORCH = 0, 1
 
 
 def conv1d(x, w, bias=None, stride=1, pad=0, dil=1, transposed=False, act=0, slope=0.0, alpha=None, norm=None,
-           device=0, mode=None):
-    """Run the MFMA conv kernel alone: x [B,Cin,L], w [Cout,Cin,k] ([Cin,Cout,k] if transposed)."""
+           device=0, mode=None, pre=False):
+    """Run the MFMA conv kernel alone: x [B,Cin,L], w [Cout,Cin,k] ([Cin,Cout,k] if transposed).  pre: stage the input
+    through a pre-split image (conv_f16x3_pre.hip; direct-A kernels only)."""
     lib = load_library()
     if mode is None:
         mode = CONV_F32 if os.environ.get("KOKOROX_CONV", "") == "f32" else CONV_F16X3
@@ -542,7 +543,7 @@ def conv1d(x, w, bias=None, stride=1, pad=0, dil=1, transposed=False, act=0, slo
     y = np.zeros((B, Cout, Lout), dtype=np.float32)
     bias, alpha, norm = _f32(bias), _f32(alpha), _f32(norm)
     _err_call(lib.kx_test_conv1d, device, _ptr(x), B, Cin, L, _ptr(w), _ptr(bias), Cout, k, stride, pad, dil,
-              1 if transposed else 0, act, float(slope), _ptr(alpha), _ptr(norm), _ptr(y), Lout, mode)
+              1 if transposed else 0, act, float(slope), _ptr(alpha), _ptr(norm), _ptr(y), Lout, mode | (0x100 if pre else 0))
     return y
 
 
@@ -563,7 +564,7 @@ def conv1d_epilogue(x, w, bias=None, pad=0, dil=1, resid=None, y_init=None, out_
 
 
 def conv1d_full(x, w, bias=None, pad=0, dil=1, act=0, slope=0.0, alpha=None, norm=None, resid=None, y_init=None,
-                out_mul=1.0, out_div=1.0, want_stats=False, lens=None, pad_ld=False, flat=False, mode=1, device=0):
+                out_mul=1.0, out_div=1.0, want_stats=False, lens=None, pad_ld=False, flat=False, mode=1, device=0, pre=False):
     """Stride-1 conv with the fused input transform (AdaIN affine + leaky / snake) AND the epilogue forms, on a ragged
     batch (lens[b] valid input columns), with pad_ld on the model's padded rows, with flat through the flat list of live
     tiles the model gives the direct-A kernels.  Returns y or (y, stats[B,Cout,2])."""
@@ -577,7 +578,7 @@ def conv1d_full(x, w, bias=None, pad=0, dil=1, act=0, slope=0.0, alpha=None, nor
     ln = None if lens is None else np.ascontiguousarray(lens, dtype=np.int32)
     _err_call(lib.kx_test_conv1d_full, device, _ptr(x), B, Cin, L, _ptr(ln), (1 if pad_ld else 0) | (2 if flat else 0), _ptr(w), _ptr(_f32(bias)),
               Cout, k, pad, dil, act, float(slope), _ptr(_f32(alpha)), _ptr(_f32(norm)), _ptr(_f32(resid)),
-              0 if y_init is None else 1, float(out_mul), float(out_div), _ptr(y), _ptr(st), mode)
+              0 if y_init is None else 1, float(out_mul), float(out_div), _ptr(y), _ptr(st), mode | (0x100 if pre else 0))
     return (y, st) if want_stats else y
 
 

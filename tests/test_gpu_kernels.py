@@ -371,6 +371,63 @@ def test_flat_tile_list_gives_the_same_bits_as_the_dense_grid(k, d, act, C, L):
         np.testing.assert_array_equal(z0, z1)
 
 
+@pytest.mark.parametrize("k,d,act,Cin,Cout,L", [(3, 1, 1, 1090, 256, 900), (3, 1, 1, 514, 384, 422), (3, 1, 0, 40, 130, 300),
+                                               (5, 3, 0, 64, 128, 1300), (2, 1, 1, 100, 128, 517)])
+def test_pre_split_image_gives_the_same_bits(k, d, act, Cin, Cout, L):
+    """Round 5: layers whose window many row tiles stage read a pre-split image of their input (conv_f16x3_pre.hip: the AdaIN
+    affine, activation and f16 hi / lo split done once by an elementwise pass, in the LDS layout) instead of transforming the
+    window in every workgroup.  Same bits as the in-kernel transform, stored values and fused statistics, on a ragged batch with
+    the model's padded rows (NaN in the padding, NaN in the image wherever the pass does not write), through the flat tile list,
+    on both tile widths (mode 1 with this grid: 128 columns; mode 3: 256 columns, the W2 form for k = 3) -- and against float64."""
+    from kokorox_amd import hip_koko as hk
+    rng = np.random.default_rng(k * 17 + Cin)
+    B = 4
+    p = d * (k - 1) // 2
+    Lo = L + 2 * p - d * (k - 1)
+    lens = np.array([L, max(1, L // 3), L - 1, 131], dtype=np.int32)
+    x = rng.standard_normal((B, Cin, L), dtype=np.float32)
+    w = (rng.standard_normal((Cout, Cin, k), dtype=np.float32) / np.sqrt(Cin * k)).astype(np.float32)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    norm = rng.standard_normal((3, B, Cin), dtype=np.float32)
+    norm[1] = 1.0 + 0.2 * norm[1]
+    res = rng.standard_normal((B, Cout, Lo), dtype=np.float32)
+    kw = dict(pad=p, dil=d, act=act, slope=0.2, lens=lens, pad_ld=True)
+    if act:
+        kw.update(norm=norm)
+    for mode in (1, 3):
+        for flat in (False, True):
+            y0, s0 = hk.conv1d_full(x, w, b, resid=res, want_stats=True, mode=mode, flat=flat, **kw)
+            y1, s1 = hk.conv1d_full(x, w, b, resid=res, want_stats=True, mode=mode, flat=flat, pre=True, **kw)
+            np.testing.assert_array_equal(y0, y1)
+            np.testing.assert_array_equal(s0, s1)
+            assert np.isfinite(y1).all() and np.abs(y1).max() > 0
+    xt = _act_ref(torch.from_numpy(x).double(), act, norm, None) if act else torch.from_numpy(x).double()
+    for i in range(B):
+        n = int(lens[i])
+        ref = F.conv1d(xt[i:i + 1, :, :n], torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=p, dilation=d).numpy()[0]
+        no = n + Lo - L
+        assert np.abs(y1[i, :, :no] - (ref + res[i, :, :no])).max() < 3e-5
+
+
+@pytest.mark.parametrize("Cin,Cout,L,s", [(512, 256, 50, 10), (256, 128, 300, 6), (24, 20, 37, 10)])
+def test_pre_split_image_polyphase_same_bits(Cin, Cout, L, s):
+    """The polyphase transposed convs (run-time-tap form, 20 / 6 row tiles per window in the model) through a pre-split image:
+    same bits as the in-kernel transform (leaky 0.1, no norm: what Generator.ups reads), both tile widths, and against float64."""
+    from kokorox_amd import hip_koko as hk
+    rng = np.random.default_rng(Cin + L)
+    k = 2 * s
+    x = rng.standard_normal((3, Cin, L), dtype=np.float32)
+    w = (rng.standard_normal((Cin, Cout, k), dtype=np.float32) / np.sqrt(Cin * 2)).astype(np.float32)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    for mode in (1, 3):
+        y0 = hk.conv1d(x, w, b, stride=s, pad=(k - s) // 2, transposed=True, act=1, slope=0.1, mode=mode)
+        y1 = hk.conv1d(x, w, b, stride=s, pad=(k - s) // 2, transposed=True, act=1, slope=0.1, mode=mode, pre=True)
+        np.testing.assert_array_equal(y0, y1)
+    ref = F.conv_transpose1d(F.leaky_relu(torch.from_numpy(x).double(), 0.1), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                             stride=s, padding=(k - s) // 2).numpy()
+    assert np.abs(y1 - ref).max() < 2e-5
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("k,d,act,Cin,Cout,L", [(3, 1, 1, 40, 130, 300), (7, 3, 2, 48, 128, 517), (11, 5, 2, 64, 256, 700),
                                                (5, 1, 0, 130, 64, 129), (3, 5, 2, 128, 128, 1025), (7, 1, 2, 20, 22, 513)])
