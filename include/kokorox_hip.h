@@ -282,11 +282,20 @@ int kx_debug_tap(kx_model* m, const char* name, int b, float* out, int64_t out_c
  * or, for transposed = 1, [Cin,Cout,k]); y must hold B*Cout*Lout floats.  act: 0 none,
  * 1 leaky(slope), 2 snake(alpha[Cin]); norm = optional [3,B,Cin] (mean, scale, shift);
  * mode as in kx_set_conv_mode, plus 2 = f16x3 on the LDS-DMA kernel forms only (conv_f16x3.hip: what the direct-A
- * kernels are compared with bit for bit) and 3 = f16x3 through the direct-A kernel whatever the grid. */
+ * kernels are compared with bit for bit) and 3 = f16x3 through the direct-A kernel whatever the grid; + 0x100 (modes 1 and 3,
+ * here and in the other conv hooks) = the input staged through a pre-split image (conv_f16x3_pre.hip) whatever the row count. */
 int kx_test_conv1d(int device_id, const float* x, int B, int Cin, int L, const float* w,
                    const float* bias, int Cout, int k, int stride, int pad, int dil,
                    int transposed, int act, float slope, const float* alpha,
                    const float* norm, float* y, int Lout, int mode, char* err, size_t err_len);
+
+/* A polyphase transposed conv (k = 2 stride, pad = stride / 2) as the generator's upsamplers run it: x [B,Cin,L], w [Cin,Cout,k],
+ * fused leaky input activation, residual [B,Cout,Ly] added in the scatter store; up_off = 1: the output starts at column 1 of y
+ * and column 0 is its reflection (ReflectionPad1d((1, 0)), the last upsampler), Ly = Lout + up_off, Lout = (L-1) stride - 2 pad + k.
+ * mode as kx_test_conv1d, + 0x100 = through a pre-split input image. */
+int kx_test_conv_transpose(int device_id, const float* x, int B, int Cin, int L, const float* w, const float* bias, int Cout,
+                           int stride, int act, float slope, const float* resid, int up_off, float* y, int mode, char* err,
+                           size_t err_len);
 
 /* The epilogue forms of the same kernel on a stride-1 conv: y = (conv + bias + resid [+ y]) * out_mul / out_div
  * with y [B,Cout,Lout] (Lout = L + 2 pad - dil (k-1)) read as the running sum when accumulate != 0, and - when

@@ -384,6 +384,7 @@ struct ConvTestExtra {  // epilogue forms beyond bias: residual, accumulate into
     const int32_t* lens = nullptr;  // [B] valid input columns per utterance (ragged batch); null = all L
     int pad_ld = 0;              // rows padded to a multiple of 32 floats as in the model (x padding = NaN, y padding checked)
     int flat = 0;                // ragged batches: the flat tile list the model gives the direct-A kernels (ConvArgs::tile_prefix)
+    int up_off = 0, up_reflect = 0;  // transposed: the output starts at column up_off of y (and column 0 = reflection of column 1)
 };
 }  // namespace
 
@@ -405,7 +406,9 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
         kx::ConvArgs a{};
         a.ws_force = mode == kx::CONV_F16X3_LDS ? 1 : (mode == kx::CONV_F16X3_DA ? 2 : 0);
         // row strides: the caller's dense rows, or (pad_ld) the model's: a multiple of 32 floats, input padding poisoned
-        const int x_ld = ex.pad_ld ? (L + 31) & ~31 : L, y_ld = ex.pad_ld ? (Lout + 31) & ~31 : Lout;
+        const int Ly = Lout + ex.up_off;  // columns of y (Lout: the conv's own output length)
+        KX_REQUIRE(ex.up_off == 0 || (transposed && ex.up_off == 1 && !ex.pad_ld), "test_conv1d: an output offset comes with transposed convs");
+        const int x_ld = ex.pad_ld ? (L + 31) & ~31 : L, y_ld = ex.pad_ld ? (Lout + 31) & ~31 : Ly;
         const float poison = std::nanf(""), sentinel = -12345.5f;
         auto padded = [&](const float* src, int rows_total, int len, int ld, float fill) {
             std::vector<float> v((size_t)rows_total * ld, fill);
@@ -460,6 +463,8 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
             a.up_s = stride;
             a.up_pad = pad;
             a.up_cout = Cout;
+            a.up_off = ex.up_off;
+            a.up_reflect = ex.up_reflect;
         }
         a.Cout = rows;
         a.w = packed;
@@ -483,7 +488,7 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
         } else if (ex.accum)
             KX_HIP(hipMemcpy(dy, y, (size_t)B * Cout * Lout * 4, hipMemcpyHostToDevice));  // y holds the running sum
         else
-            KX_HIP(hipMemset(dy, 0, (size_t)B * Cout * Lout * 4));
+            KX_HIP(hipMemset(dy, 0, (size_t)B * Cout * Ly * 4));
         a.y = dy;
         a.y_bs = (long)Cout * y_ld;
         a.y_ld = y_ld;
@@ -491,12 +496,12 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
         a.out_div = ex.out_div;
         a.accum = ex.accum;
         if (ex.resid) {
-            KX_REQUIRE(!transposed, "test_conv1d: residual with the plain conv only");
+            KX_REQUIRE(!transposed || !ex.pad_ld, "test_conv1d: residual of a transposed conv on dense rows only");
             if (ex.pad_ld) {
                 const std::vector<float> rp = padded(ex.resid, B * Cout, Lout, y_ld, poison);
                 a.resid = dm.up(rp.data(), rp.size());
             } else
-                a.resid = dm.up(ex.resid, (size_t)B * Cout * Lout);
+                a.resid = dm.up(ex.resid, (size_t)B * Cout * Ly);
             a.r_bs = (long)Cout * y_ld;
             a.r_ld = y_ld;
         }
@@ -577,7 +582,7 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
                     if (yp[(size_t)r * y_ld + c] != sentinel) throw Error(KX_ERR_STATE, "test_conv1d: the kernel wrote into the row padding");
             }
         } else
-            KX_HIP(hipMemcpy(y, dy, (size_t)B * Cout * Lout * 4, hipMemcpyDeviceToHost));
+            KX_HIP(hipMemcpy(y, dy, (size_t)B * Cout * Ly * 4, hipMemcpyDeviceToHost));
         if (ex.stats_out) {
             std::vector<float2> part((size_t)B * rows * a.stat_tiles);
             KX_HIP(hipMemcpy(part.data(), d_part, part.size() * sizeof(float2), hipMemcpyDeviceToHost));
@@ -600,6 +605,19 @@ int kx_test_conv1d(int device_id, const float* x, int B, int Cin, int L, const f
                    const float* norm, float* y, int Lout, int mode, char* err, size_t err_len) {
     return test_conv1d_impl(device_id, x, B, Cin, L, w, bias, Cout, k, stride, pad, dil, transposed, act, slope, alpha, norm,
                             y, Lout, mode, ConvTestExtra{}, err, err_len);
+}
+
+int kx_test_conv_transpose(int device_id, const float* x, int B, int Cin, int L, const float* w, const float* bias, int Cout,
+                           int stride, int act, float slope, const float* resid, int up_off, float* y, int mode, char* err,
+                           size_t err_len) {
+    ConvTestExtra ex;
+    ex.resid = resid;
+    ex.up_off = up_off ? 1 : 0;
+    ex.up_reflect = up_off ? 1 : 0;
+    const int k = 2 * stride, pad = (k - stride) / 2;
+    const int Lout = (L - 1) * stride - 2 * pad + k;
+    return test_conv1d_impl(device_id, x, B, Cin, L, w, bias, Cout, k, stride, pad, 1, 1, act, slope, nullptr, nullptr, y, Lout, mode, ex,
+                            err, err_len);
 }
 
 int kx_test_conv1d_epilogue(int device_id, const float* x, int B, int Cin, int L, const float* w, const float* bias,

@@ -463,11 +463,6 @@ void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int
         *bn = 256; *wn = 2;
         return;
     }
-    static const int k3_narrow = env_int("KX_K3_BN128", 0);  // experiment: the 3-tap snake convs on the 128-column tile (three workgroups per CU)
-    if (k3_narrow && BM == 128 && K == 3 && act == ACT_SNAKE && stride == 1 && ws_force == 0) {
-        *bn = 128; *wn = 1;
-        return;
-    }
     if (BM != 128) {
         *bn = 256; *wn = 4;
     } else if ((force == 128 || max_cols <= 160) && !stats) {

@@ -114,6 +114,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                  i32, i32, cp, sz]),
         "kx_test_conv1d_full": (i32, [i32, vp, i32, i32, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, i32, f32,
                                       f32, vp, vp, i32, cp, sz]),
+        "kx_test_conv_transpose": (i32, [i32, vp, i32, i32, i32, vp, vp, i32, i32, i32, f32, vp, i32, vp, i32, cp, sz]),
         "kx_test_lstm": (i32, [i32, vp, i32, i32, i32] + [vp] * 9 + [cp, sz]),
         "kx_test_source": (i32, [i32, vp, i32, i32, vp, f32, u64, u64, i32, vp, cp, sz]),
         "kx_test_attention": (i32, [i32, vp, vp, i32, i32, vp, cp, sz]),
@@ -137,7 +138,7 @@ ABI_SYMBOLS = [
     "kx_set_conv_mode", "kx_get_conv_mode", "kx_set_stft_variant", "kx_get_stft_variant",
     "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_profile_aux", "kx_diag_enable", "kx_diag_count", "kx_diag_get", "kx_set_act_prescale", "kx_set_voice_table", "kx_infer_voices",
     "kx_infer_packed", "kx_free_packed", "kx_dispatcher_create", "kx_dispatcher_submit", "kx_dispatcher_submit_ex", "kx_dispatcher_model_batches",
-    "kx_dispatcher_stats", "kx_dispatcher_failures", "kx_dispatcher_destroy", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test_attention", "kx_test_conv1d_epilogue", "kx_test_conv1d_full", "kx_test_lstm_fault",
+    "kx_dispatcher_stats", "kx_dispatcher_failures", "kx_dispatcher_destroy", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test_attention", "kx_test_conv1d_epilogue", "kx_test_conv1d_full", "kx_test_conv_transpose", "kx_test_lstm_fault",
 ]
 
 
@@ -544,6 +545,22 @@ def conv1d(x, w, bias=None, stride=1, pad=0, dil=1, transposed=False, act=0, slo
     bias, alpha, norm = _f32(bias), _f32(alpha), _f32(norm)
     _err_call(lib.kx_test_conv1d, device, _ptr(x), B, Cin, L, _ptr(w), _ptr(bias), Cout, k, stride, pad, dil,
               1 if transposed else 0, act, float(slope), _ptr(alpha), _ptr(norm), _ptr(y), Lout, mode | (0x100 if pre else 0))
+    return y
+
+
+def conv_transpose(x, w, bias=None, stride=6, act=1, slope=0.1, resid=None, up_off=0, mode=1, pre=False, device=0):
+    """Polyphase transposed conv as Generator.ups runs it: x [B,Cin,L], w [Cin,Cout,2*stride] -> y [B,Cout,Lout + up_off]
+    (+ resid; up_off = 1: output from column 1, column 0 = reflection of column 1)."""
+    lib = load_library()
+    x, w = _f32(x), _f32(w)
+    B, Cin, L = x.shape
+    Cout, k = w.shape[1], w.shape[2]
+    assert k == 2 * stride
+    pad = (k - stride) // 2
+    Lout = (L - 1) * stride - 2 * pad + k
+    y = np.zeros((B, Cout, Lout + (1 if up_off else 0)), dtype=np.float32)
+    _err_call(lib.kx_test_conv_transpose, device, _ptr(x), B, Cin, L, _ptr(w), _ptr(_f32(bias)), Cout, stride, act, float(slope),
+              _ptr(_f32(resid)), 1 if up_off else 0, _ptr(y), mode | (0x100 if pre else 0))
     return y
 
 

@@ -409,6 +409,33 @@ def test_pre_split_image_gives_the_same_bits(k, d, act, Cin, Cout, L):
         assert np.abs(y1[i, :, :no] - (ref + res[i, :, :no])).max() < 3e-5
 
 
+@pytest.mark.parametrize("B,Cin,Cout,L,s,up_off", [(8, 64, 128, 2100, 6, 1), (8, 48, 256, 1300, 10, 0), (1, 32, 128, 2100, 6, 1),
+                                                   (2, 32, 52, 1500, 10, 0)])
+def test_polyphase_with_residual_offset_and_reflection(B, Cin, Cout, L, s, up_off):
+    """The polyphase transposed convs as Generator.ups runs them -- residual added in the scatter store, the output offset and
+    reflected first column of the last upsampler, row tiles that cut channels (128 / 6, 128 / 10), both tile widths (mode 1 at
+    B = 1: 128 columns), with and without the pre-split input image -- bit for bit against the LDS-DMA kernel form (mode 2), and
+    against float64."""
+    from kokorox_amd import hip_koko as hk
+    rng = np.random.default_rng(L + s)
+    k = 2 * s
+    x = rng.standard_normal((B, Cin, L), dtype=np.float32)
+    w = (rng.standard_normal((Cin, Cout, k), dtype=np.float32) / np.sqrt(Cin * 2)).astype(np.float32)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    Lout = (L - 1) * s - 2 * ((k - s) // 2) + k
+    res = rng.standard_normal((B, Cout, Lout + up_off), dtype=np.float32)
+    y2 = hk.conv_transpose(x, w, b, stride=s, resid=res, up_off=up_off, mode=2)
+    for mode in (1, 3):
+        for pre in (False, True):
+            y = hk.conv_transpose(x, w, b, stride=s, resid=res, up_off=up_off, mode=mode, pre=pre)
+            np.testing.assert_array_equal(y2, y)
+    ref = F.conv_transpose1d(F.leaky_relu(torch.from_numpy(x).double(), 0.1), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                             stride=s, padding=(k - s) // 2)
+    if up_off:
+        ref = torch.cat([ref[..., 1:2], ref], dim=-1)
+    assert np.abs(y - (ref.numpy() + res)).max() < 2e-5
+
+
 @pytest.mark.parametrize("Cin,Cout,L,s", [(512, 256, 50, 10), (256, 128, 300, 6), (24, 20, 37, 10)])
 def test_pre_split_image_polyphase_same_bits(Cin, Cout, L, s):
     """The polyphase transposed convs (run-time-tap form, 20 / 6 row tiles per window in the model) through a pre-split image:
