@@ -247,11 +247,20 @@ __global__ __launch_bounds__(256, 3) void conv1d_f16x3_dag_kernel(const ConvArgs
 // / padding / f16 split (xform values are those of xform_pair, operation for operation) and feeds the wave's three MFMAs; the
 // four waves (32 rows each) repeat that split, which is cheaper than a barrier.  Weights and inputs come through a three-slot
 // register ring of inline-asm loads, ten per chunk (2 weight fragments + 8 input values), every one unconditional (chunks past
-// the end re-read the last chunk and are multiplied by zero), so the waits are constants: vmcnt(10), the one younger slot.
+// the end re-read the last chunk and are multiplied by zero), so the waits are constants: vmcnt(10 (R - 2)), the younger slots.
 // Per accumulator the products are added in the order of the other forms: results are bit-identical to them.
+// Ring depth R (round 5: 3 -> 6).  A workgroup of this form walks K alone and nothing hides a load but the ring: with three
+// slots a chunk's loads had two chunks (~0.35 us of work) to come back from L2 and the walk ran at the latency, 0.69 us per chunk
+// (profiles/r05_b1_timeline_before.txt: 33 us for the 48 chunks of the 2304 x 768 launch, 56 such launches on the batch-1
+// critical path); six slots give them five.  96 registers of ring: three workgroups per CU instead of four, on grids that have
+// at most half a workgroup per CU anyway.
+#ifndef KX_DAGN_RING
+#define KX_DAGN_RING 6
+#endif
 template <int ACT>
-__global__ __launch_bounds__(256, 4) void conv1d_f16x3_dagn_kernel(const ConvArgs a) {
-    constexpr int BM = 128, BN = 32;
+__global__ __launch_bounds__(256, 3) void conv1d_f16x3_dagn_kernel(const ConvArgs a) {
+    constexpr int BM = 128, BN = 32, R = KX_DAGN_RING;
+    static_assert(R >= 3 && 10 * (R - 1) <= 63, "ring depth: the waits must fit vmcnt");
     constexpr int tap_units = 4 * BM;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(256, 4) void conv1d_f16x3_dagn_kernel(const ConvArg
     const int ncols = Lout;
     if (t0 >= ncols) return;
     const int n_chunks = a.n_chunks16;
-    const int n_super = (n_chunks + 2) / 3;
+    const int n_super = (n_chunks + R - 1) / R;
 
     // the lane's input column (a 1-tap GEMM has no padding)
     long xoff;
@@ -293,8 +302,8 @@ __global__ __launch_bounds__(256, 4) void conv1d_f16x3_dagn_kernel(const ConvArg
     for (int j = 0; j < 8; ++j) voff[j] = (unsigned)(((long)(h * 8 + j) * a.x_ld + xoff) * 4);
     const uint4* wlane = reinterpret_cast<const uint4*>(a.w16) + (long)ct * n_chunks * tap_units + h * BM + wave * 32 + r;
     using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-    u32x4 ahs[3], als[3];
-    float raw[3][8];
+    u32x4 ahs[R], als[R];
+    float raw[R][8];
     // chunk c into a slot: ten vector loads, whatever c
     auto load_chunk = [&](int c, u32x4& a_hi, u32x4& a_lo, float (&rw)[8]) __attribute__((always_inline)) {
         const int cc = c < n_chunks ? c : n_chunks - 1;
@@ -306,9 +315,10 @@ __global__ __launch_bounds__(256, 4) void conv1d_f16x3_dagn_kernel(const ConvArg
         for (int j = 0; j < 8; ++j) asm volatile("global_load_dword %0, %1, %2" : "=v"(rw[j]) : "v"(voff[j]), "s"(base) : "memory");
     };
     // (the wait has no operands, a scheduling barrier follows, and only then are the registers handed on: conv_f16x3_da.hip)
-    auto wait_chunk = [&](const int n, u32x4& a_hi, u32x4& a_lo, float (&rw)[8]) __attribute__((always_inline)) {
-        if (n == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    auto wait_chunk = [&](const bool first, u32x4& a_hi, u32x4& a_lo, float (&rw)[8]) __attribute__((always_inline)) {
+        // (first: the ring has just been filled, R - 1 younger slots; else the R - 2 slots issued since this one's refill)
+        if (first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 * (R - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 * (R - 2)) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" : "+v"(a_hi), "+v"(a_lo), "+v"(rw[0]), "+v"(rw[1]), "+v"(rw[2]), "+v"(rw[3]), "+v"(rw[4]), "+v"(rw[5]), "+v"(rw[6]),
                      "+v"(rw[7]));
@@ -330,22 +340,23 @@ __global__ __launch_bounds__(256, 4) void conv1d_f16x3_dagn_kernel(const ConvArg
     f32x16 acc[1][1];
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.f;
-    load_chunk(0, ahs[0], als[0], raw[0]);
-    load_chunk(1, ahs[1], als[1], raw[1]);
-    load_chunk(2, ahs[2], als[2], raw[2]);
+    static_for_g<0, R>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        load_chunk(t, ahs[t], als[t], raw[t]);
+    });
     half8 bh, bl;
-    wait_chunk(20, ahs[0], als[0], raw[0]);
+    wait_chunk(true, ahs[0], als[0], raw[0]);
     split8(0, raw[0], bh, bl);
     for (int sc = 0; sc < n_super; ++sc) {
-        static_for_g<0, 3>([&](auto tc) __attribute__((always_inline)) {
-            constexpr int t = decltype(tc)::value, tn = (t + 1) % 3;
-            const int c = sc * 3 + t;
+        static_for_g<0, R>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value, tn = (t + 1) % R;
+            const int c = sc * R + t;
             const half8 ah = __builtin_bit_cast(half8, ahs[t]), al = __builtin_bit_cast(half8, als[t]);
             const half8 bh0 = bh, bl0 = bl;
             // The three MFMAs of a chunk are a dependent chain on the one accumulator: each waits for the one before it, and
-            // the split of the NEXT chunk's fragment (slot tn: the only younger loads are slot t + 2's ten) fills the gaps.
+            // the split of the NEXT chunk's fragment (slot tn: the younger loads are those of the R - 2 slots behind it) fills the gaps.
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh0, acc[0][0], 0, 0, 0);
-            wait_chunk(10, ahs[tn], als[tn], raw[tn]);
+            wait_chunk(false, ahs[tn], als[tn], raw[tn]);
             split8(c + 1, raw[tn], bh, bl);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl0, acc[0][0], 0, 0, 0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh0, acc[0][0], 0, 0, 0);
@@ -355,12 +366,12 @@ __global__ __launch_bounds__(256, 4) void conv1d_f16x3_dagn_kernel(const ConvArg
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_barrier(0);
             // slot t is free once its MFMAs are issued (they read ah / al when they issue)
-            load_chunk(c + 3, ahs[t], als[t], raw[t]);
+            load_chunk(c + R, ahs[t], als[t], raw[t]);
         });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int sl = 0; sl < 3; ++sl)  // (the ring's last loads land in registers that stay reserved until here)
+    for (int sl = 0; sl < R; ++sl)  // (the ring's last loads land in registers that stay reserved until here)
         asm volatile("" ::"v"(ahs[sl]), "v"(als[sl]), "v"(raw[sl][0]), "v"(raw[sl][1]), "v"(raw[sl][2]), "v"(raw[sl][3]), "v"(raw[sl][4]),
                      "v"(raw[sl][5]), "v"(raw[sl][6]), "v"(raw[sl][7]));
     conv_store_tile<1, 1, EPI_ROWS, true>(a, acc, a.w_unscale, b, ct * BM + wave * 32, t0, r, h, ncols, Lout, tile_x, nullptr);

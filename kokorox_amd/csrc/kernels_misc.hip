@@ -624,47 +624,64 @@ __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gx_bs,
 // can only be one step ahead of its partner).  The two halves are blocks i and i + 8 of a group of 16 (same XCD);
 // blocks are dispatched in order, so at most eight pairs per launch ever wait for a partner that is not resident yet.  Every poll is bounded: if the
 // partner never shows up the half raises the model's sticky error word and leaves (an error, never a hang).
-constexpr int LSTMP_REG = 24;           // float4 (4 k) pieces of a thread's 32 held in registers, the rest in LDS
-constexpr int LSTMP_LDS = 32 - LSTMP_REG;
+// Round 5: the same recurrence on FOUR workgroups (NQ = 4) for batches whose pairs leave CUs idle.  A step of the two-CU form is
+// bound by the CU's LDS return path (1024 lanes x 24 16-byte reads: 16 of h, 8 of the weight tail that does not fit the 128
+// registers a 1024-thread workgroup leaves a lane; packed fmas instead of scalar ones changed nothing: profiles/
+// r05_experiments_not_kept.txt).  A quarter owns 64 hidden units = 256 gate rows on 512 threads, which may hold 256 registers
+// each: ALL of a lane's 128 weights live in registers, the LDS traffic of a step falls to the 16 reads of h of half as many
+// lanes, and four CUs share the step.  A lane's arithmetic is that of the two-CU form, operation for operation (two rows x a K
+// quarter, the same order of sums): both forms give the same bits, and which one runs may depend on the batch (launch_lstm).
+// Parts p of a (utterance, direction) are blocks i + 8 p of a group of 8 NQ blocks (one XCD); blocks are dispatched in order.
+template <int NQ>
+struct LstmParts {
+    static constexpr int HU = 256 / NQ;            // hidden units of a part
+    static constexpr int ROWS = 4 * HU;            // its gate rows
+    static constexpr int THREADS = 2 * ROWS;       // lanes: (row pair, K quarter)
+    static constexpr int REG = NQ == 2 ? 24 : 32;  // float4 (4 k) pieces of a lane's 32 held in registers, the rest in LDS
+    static constexpr int LDSP = 32 - REG;
+};
 constexpr int LSTMP_HP = 68;            // pitch of a K quarter of h in LDS (64 values + 4: bank offset between the quarters)
-__global__ __launch_bounds__(1024) void lstm_pair_kernel(const float* gx, long gx_bs, int gx_ld, const float* whhT,
+template <int NQ>
+__global__ __launch_bounds__(LstmParts<NQ>::THREADS) void lstm_pair_kernel(const float* gx, long gx_bs, int gx_ld, const float* whhT,
                                                          float* y, long y_bs, int y_ld, LenMap len,
                                                          unsigned long long* xchg, unsigned epoch, unsigned* err,
                                                          int n_pairs, int spin_limit, int drop_half) {
+    using P = LstmParts<NQ>;
+    constexpr int HU = P::HU, ROWS = P::ROWS, NT = P::THREADS, LSTMP_REG = P::REG, LSTMP_LDS = P::LDSP;
     extern __shared__ __attribute__((aligned(16))) float lstm_smem[];
-    // h of the previous step (both halves) in four K quarters of 64 with a pitch of 68 floats: the four lanes of a quad read
+    // h of the previous step (all parts) in four K quarters of 64 with a pitch of 68 floats: the four lanes of a quad read
     // four different quarters in one instruction, and 272 bytes apart they sit in different banks
     float* hs = lstm_smem;                                   // [4][LSTMP_HP]
-    float* gates = hs + 4 * LSTMP_HP;                        // [512] gate pre-activations of this half
-    int* abort_flag = reinterpret_cast<int*>(gates + 512);   // [4] (one word used): a poll timed out
-    float4* wl = reinterpret_cast<float4*>(gates + 512 + 4); // [LSTMP_LDS][1024] x 4 k: the tail of every thread's 128 weights
-    // The two halves of a pair are blocks i and i + 8 of a group of 16: blocks are dealt round-robin over the 8 XCDs, so
-    // both halves share one XCD's L2 and the hand-off does not cross the fabric (speed only: nothing depends on it).
-    const int hf = (blockIdx.x >> 3) & 1, pair = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);  // pair = b * 2 + dir
+    float* gates = hs + 4 * LSTMP_HP;                        // [ROWS] gate pre-activations of this part
+    int* abort_flag = reinterpret_cast<int*>(gates + ROWS);  // [4] (one word used): a poll timed out
+    float4* wl = reinterpret_cast<float4*>(gates + ROWS + 4); // [LSTMP_LDS][NT] x 4 k: the tail of every thread's 128 weights (NQ = 2)
+    // The parts of a pair are blocks i + 8 p of a group of 8 NQ: blocks are dealt round-robin over the 8 XCDs, so all parts
+    // share one XCD's L2 and the hand-off does not cross the fabric (speed only: nothing depends on it).
+    const int grp = blockIdx.x / (8 * NQ), in_grp = blockIdx.x - grp * (8 * NQ);
+    const int hf = in_grp >> 3, pair = grp * 8 + (in_grp & 7);  // pair = b * 2 + dir; hf = part
     if (pair >= n_pairs) return;                             // (padding blocks of the last group)
-    if (drop_half && hf == 1) return;                        // (test hook: the partner that never shows up)
+    if (drop_half && hf == NQ - 1) return;                   // (test hook: the partner that never shows up)
     const int b = pair >> 1, dir = pair & 1, tid = threadIdx.x;
     const int L = len_of(len, b);
     // Lane (row pair rp, K quarter kq): TWO rows x 64 k each.  Reading h from LDS is what a step costs most (round 4: with the
     // partner's values not even waited for, a step took 2.76 of its 2.94 us): every lane used to walk 128 k of ONE row, 32
     // 16-byte reads of h per step and lane; with two rows per lane a value of h read once feeds two rows: 16 reads.  The four
     // quarters of a row are the four lanes of a quad and meet in two DPP adds: (q0 + q1) + (q2 + q3).
-    const int kq = tid & 3, rp = tid >> 2;                   // rows 2 rp, 2 rp + 1 of the half's 512 (gate r >> 7, unit r & 127)
-    auto wrow = [&](int rr) { return (rr >> 7) * 256 + hf * 128 + (rr & 127); };  // row of W_hh / column of gx
+    const int kq = tid & 3, rp = tid >> 2;                   // rows 2 rp, 2 rp + 1 of the part's ROWS (gate r / HU, unit r % HU)
+    auto wrow = [&](int rr) { return (rr / HU) * 256 + hf * HU + (rr % HU); };  // row of W_hh / column of gx
     const int rowA = wrow(2 * rp), rowB = wrow(2 * rp + 1);
     // image [k4][row][4 k] (launch_transpose_whh): k4 = 16 kq + j covers the lane's 64 k
     const float4* W4 = reinterpret_cast<const float4*>(whhT + (long)dir * 256 * 1024) + (long)kq * 16 * 1024;
-    float4 wreg[LSTMP_REG];  // pieces 2 j + s (s: row A / B), the first 24 in registers, the last 8 (j = 12 .. 15) in LDS
+    float4 wreg[LSTMP_REG];  // pieces 2 j + s (s: row A / B), the first LSTMP_REG in registers, the rest in LDS
 #pragma unroll
     for (int i = 0; i < LSTMP_REG; ++i) wreg[i] = W4[(long)(i >> 1) * 1024 + ((i & 1) ? rowB : rowA)];
 #pragma unroll
-    for (int i = 0; i < LSTMP_LDS; ++i) wl[i * 1024 + tid] = W4[(long)((LSTMP_REG + i) >> 1) * 1024 + ((i & 1) ? rowB : rowA)];
+    for (int i = 0; i < LSTMP_LDS; ++i) wl[i * NT + tid] = W4[(long)((LSTMP_REG + i) >> 1) * 1024 + ((i & 1) ? rowB : rowA)];
     if (tid < 4 * LSTMP_HP) hs[tid] = 0.f;
     if (tid == 0) *abort_flag = 0;
     float c = 0.f;
-    // exchange slots: [pair][parity][half][128] granules
-    unsigned long long* mine = xchg + (((long)pair * 2) * 2 + hf) * 128;       // + parity * 256
-    unsigned long long* theirs = xchg + (((long)pair * 2) * 2 + (1 - hf)) * 128;
+    // exchange slots: [pair][parity][256] granules, unit u of the hidden state at index u (part u / HU writes it)
+    unsigned long long* slots = xchg + (long)pair * 2 * 256;  // + parity * 256
     // lanes kq = 0 / 1 of a quad finish row A / B: they carry its input projection
     const int my_rr = 2 * rp + (kq & 1);
     const float* gxp = gx + b * gx_bs + dir * 1024 + ((kq & 1) ? rowB : rowA);
@@ -691,7 +708,7 @@ __global__ __launch_bounds__(1024) void lstm_pair_kernel(const float* gx, long g
 #pragma unroll
         for (int j = 0; j < LSTMP_LDS / 2; ++j) {
             const float4 hv = h4[LSTMP_REG / 2 + j];
-            const float4 wa = wl[(2 * j) * 1024 + tid], wb = wl[(2 * j + 1) * 1024 + tid];
+            const float4 wa = wl[(2 * j) * NT + tid], wb = wl[(2 * j + 1) * NT + tid];
             accA = fmaf(wa.x, hv.x, accA);
             accB = fmaf(wb.x, hv.x, accB);
             accA = fmaf(wa.y, hv.y, accA);
@@ -714,26 +731,27 @@ __global__ __launch_bounds__(1024) void lstm_pair_kernel(const float* gx, long g
         __syncthreads();
         const unsigned tag = (epoch << 16) | (unsigned)(step + 1);
         const int par = step & 1;
-        if (tid < 128) {
+        if (tid < HU) {
             const float ig = 1.0f / (1.0f + expf(-gates[tid]));
-            const float fg = 1.0f / (1.0f + expf(-gates[128 + tid]));
-            const float gg = tanhf(gates[256 + tid]);
-            const float og = 1.0f / (1.0f + expf(-gates[384 + tid]));
+            const float fg = 1.0f / (1.0f + expf(-gates[HU + tid]));
+            const float gg = tanhf(gates[2 * HU + tid]);
+            const float og = 1.0f / (1.0f + expf(-gates[3 * HU + tid]));
             c = fg * c + ig * gg;
             const float hn = og * tanhf(c);
-            if (step + 1 < L) {  // publish for the partner's next step first: one 8-byte agent-scope store
+            if (step + 1 < L) {  // publish for the partners' next step first: one 8-byte agent-scope store
                 const unsigned long long g8 = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(hn);
-                __hip_atomic_store(mine + par * 256 + tid, g8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(slots + par * 256 + hf * HU + tid, g8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            hs[hslot(hf * 128 + tid)] = hn;
-            y[b * y_bs + (long)(dir * 256 + hf * 128 + tid) * y_ld + t] = hn;
+            hs[hslot(hf * HU + tid)] = hn;
+            y[b * y_bs + (long)(dir * 256 + hf * HU + tid) * y_ld + t] = hn;
         } else if (tid < 256 && step + 1 < L) {
-            // threads 128..255 fetch the partner's half: poll each granule until it carries this step's tag
-            const int j = tid - 128;
+            // threads HU .. 255 fetch the partners' units: poll each granule until it carries this step's tag
+            const int j = tid - HU;                        // 0 .. 255 - HU over the units that are not this part's
+            const int u = j < hf * HU ? j : j + HU;
             unsigned long long g8 = 0;
             int spins = 0;
             for (;;) {
-                g8 = __hip_atomic_load(theirs + par * 256 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g8 = __hip_atomic_load(slots + par * 256 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)(g8 >> 32) == tag) break;
                 if (++spins > spin_limit) {  // (1 << 22 ~ seconds: the partner is not coming)
                     atomicOr(err, 2u);
@@ -743,7 +761,7 @@ __global__ __launch_bounds__(1024) void lstm_pair_kernel(const float* gx, long g
                 }
                 if (spins > 64) __builtin_amdgcn_s_sleep(1);  // (a tight poll while the partner is a fraction of a step away)
             }
-            hs[hslot((1 - hf) * 128 + j)] = __uint_as_float((unsigned)(g8 & 0xffffffffu));
+            hs[hslot(u)] = __uint_as_float((unsigned)(g8 & 0xffffffffu));
         }
         __syncthreads();
         if (*abort_flag) return;  // (workgroup-uniform: written before the barrier above)
@@ -756,6 +774,10 @@ __global__ __launch_bounds__(1024) void lstm_pair_kernel(const float* gx, long g
 static std::atomic<int> lstm_test_fault{0};
 void lstm_set_test_fault(int nth) { lstm_test_fault.store(nth > 0 ? nth : 0); }
 
+// 0 = by batch size, 2 / 4 = that many workgroups per (utterance, direction) (KX_LSTM_PARTS; kx_test_lstm_parts)
+static std::atomic<int> lstm_parts_force{getenv("KX_LSTM_PARTS") ? atoi(getenv("KX_LSTM_PARTS")) : 0};
+void lstm_set_parts(int n) { lstm_parts_force.store(n == 2 || n == 4 ? n : 0); }
+
 static bool lstm_use_pair() {
     static const int v = getenv("KX_LSTM_PAIR") ? atoi(getenv("KX_LSTM_PAIR")) : 1;
     return v != 0;
@@ -767,9 +789,6 @@ void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, floa
                  LenMap len, int B, unsigned long long* xchg, unsigned* err_word, hipStream_t s, unsigned* epoch_state) {
     static_assert(LSTM_LDS_K % 4 == 0 && LSTM_REG_K % 4 == 0, "whole float4 groups of h");
     if (lstm_use_pair() && xchg && err_word) {
-        const size_t lds = sizeof(float) * (4 * LSTMP_HP + 512 + 4 + (size_t)LSTMP_LDS * 1024 * 4);
-        static DynLdsLimit pair_limit;  // (per device: each GPU's model launches from its own host thread)
-        pair_limit.ensure(reinterpret_cast<const void*>(lstm_pair_kernel), lds);
         // The tag's epoch is 16 bits wide and counted PER exchange buffer (epoch_state; the test hook's one-shot buffer has
         // none): when it wraps the buffer is cleared in stream order, so a granule of 65535 launches ago can never carry
         // the tag of a live step.  (0 is what a cleared buffer holds and is never used as an epoch.)
@@ -791,8 +810,25 @@ void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, floa
             lstm_test_fault.store(fault - 1);
             fault = 0;
         }
-        hipLaunchKernelGGL(lstm_pair_kernel, dim3(((n_pairs + 7) / 8) * 16), dim3(1024), lds, s, gx, gx_bs, gx_ld, whhT, y, y_bs,
-                           y_ld, len, xchg, epoch, err_word, n_pairs, fault ? (1 << 10) : (1 << 22), fault);
+        // Four parts per (utterance, direction) while that leaves no CU without work: 8 B workgroups of 512 threads, each of which
+        // needs a CU's whole register file (256 registers per lane).  Same bits either way (see lstm_pair_kernel).
+        // KX_LSTM_PARTS = 2 / 4 forces a form.
+        const int parts = lstm_parts_force.load();
+        const bool four = parts ? parts == 4 : 8 * B <= conv16_cu_count();
+        const int spin = fault ? (1 << 10) : (1 << 22);
+        if (four) {
+            using P4 = LstmParts<4>;
+            const size_t lds = sizeof(float) * (4 * LSTMP_HP + P4::ROWS + 4 + (size_t)P4::LDSP * P4::THREADS * 4);
+            hipLaunchKernelGGL(lstm_pair_kernel<4>, dim3(((n_pairs + 7) / 8) * 32), dim3(P4::THREADS), lds, s, gx, gx_bs, gx_ld, whhT, y,
+                               y_bs, y_ld, len, xchg, epoch, err_word, n_pairs, spin, fault);
+        } else {
+            using P2 = LstmParts<2>;
+            const size_t lds = sizeof(float) * (4 * LSTMP_HP + P2::ROWS + 4 + (size_t)P2::LDSP * P2::THREADS * 4);
+            static DynLdsLimit pair_limit;  // (per device: each GPU's model launches from its own host thread)
+            pair_limit.ensure(reinterpret_cast<const void*>(lstm_pair_kernel<2>), lds);
+            hipLaunchKernelGGL(lstm_pair_kernel<2>, dim3(((n_pairs + 7) / 8) * 16), dim3(P2::THREADS), lds, s, gx, gx_bs, gx_ld, whhT, y,
+                               y_bs, y_ld, len, xchg, epoch, err_word, n_pairs, spin, fault);
+        }
         KX_HIP(hipGetLastError());
         return;
     }

@@ -253,6 +253,7 @@ void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, floa
                  LenMap len, int B, unsigned long long* xchg, unsigned* err_word, hipStream_t s,
                  unsigned* epoch_state = nullptr);  // epoch_state: the buffer's own launch counter (see launch_lstm)
 size_t lstm_exchange_bytes(int B);
+void lstm_set_parts(int n);       // test hook: 2 / 4 workgroups per (utterance, direction) whatever the batch, 0 = by batch size
 void lstm_set_test_fault(int on);  // test hook: the two-CU kernel's partner never shows up (bounded-poll error path)
 
 void launch_duration(const float* logits, long bs, int ld, const float* speeds, int n_speed, const int* lens,

@@ -110,6 +110,34 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_dispatcher_failures": (i32, [vp, C.POINTER(i64), C.POINTER(i64)]),
         "kx_dispatcher_destroy": (None, [vp]),
         "kx_debug_tap": (i32, [vp, cp, i32, vp, i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here = the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+TEST_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libkokorox_hip_test.so")
+_test_lib = None
+
+
+def load_test_library() -> C.CDLL:
+    """dlopen libkokorox_hip_test.so: the stand-alone kernel hooks of tests/ (include/kokorox_hip_test.h).  It links against
+    libkokorox_hip.so, which is loaded first (same torch-first rule)."""
+    global _test_lib
+    if _test_lib is not None:
+        return _test_lib
+    load_library()
+    p = os.environ.get("KX_TEST_LIB") or TEST_LIB_PATH
+    if not os.path.exists(p):
+        raise FileNotFoundError(f"{p} is missing: build it with `python -m kokorox_amd.build` (hipcc, gfx950)")
+    lib = C.CDLL(p)
+    vp, i32, i64, u32, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
+    cp, sz = C.c_char_p, C.c_size_t
+    sig = {
         "kx_test_conv1d": (i32, [i32, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp,
                                  i32, i32, cp, sz]),
         "kx_test_conv1d_full": (i32, [i32, vp, i32, i32, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, i32, f32,
@@ -121,15 +149,18 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_test_lstm_fault": (i32, [i32]),
         "kx_test_conv1d_epilogue": (i32, [i32, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, vp, i32, f32, f32, vp, vp,
                                           i32, cp, sz]),
+        "kx_test_lstm_parts": (i32, [i32]),
     }
     for name, (res, args) in sig.items():
-        fn = getattr(lib, name)  # AttributeError here = the ABI lost a symbol
+        fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if path is None:
-        _lib = lib
+    _test_lib = lib
     return lib
 
+
+TEST_ABI_SYMBOLS = ["kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test_attention", "kx_test_conv1d_epilogue", "kx_test_conv1d_full",
+                    "kx_test_conv_transpose", "kx_test_lstm_fault", "kx_test_lstm_parts"]
 
 ABI_SYMBOLS = [
     "kx_version", "kx_init", "kx_create", "kx_import_onnx", "kx_create_from_device_blob", "kx_create_replicas", "kx_destroy",
@@ -138,7 +169,7 @@ ABI_SYMBOLS = [
     "kx_set_conv_mode", "kx_get_conv_mode", "kx_set_stft_variant", "kx_get_stft_variant",
     "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_profile_aux", "kx_diag_enable", "kx_diag_count", "kx_diag_get", "kx_set_act_prescale", "kx_set_voice_table", "kx_infer_voices",
     "kx_infer_packed", "kx_free_packed", "kx_dispatcher_create", "kx_dispatcher_submit", "kx_dispatcher_submit_ex", "kx_dispatcher_model_batches",
-    "kx_dispatcher_stats", "kx_dispatcher_failures", "kx_dispatcher_destroy", "kx_debug_tap", "kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test_attention", "kx_test_conv1d_epilogue", "kx_test_conv1d_full", "kx_test_conv_transpose", "kx_test_lstm_fault",
+    "kx_dispatcher_stats", "kx_dispatcher_failures", "kx_dispatcher_destroy", "kx_debug_tap",
 ]
 
 
@@ -529,7 +560,7 @@ def conv1d(x, w, bias=None, stride=1, pad=0, dil=1, transposed=False, act=0, slo
            device=0, mode=None, pre=False):
     """Run the MFMA conv kernel alone: x [B,Cin,L], w [Cout,Cin,k] ([Cin,Cout,k] if transposed).  pre: stage the input
     through a pre-split image (conv_f16x3_pre.hip; direct-A kernels only)."""
-    lib = load_library()
+    lib = load_test_library()
     if mode is None:
         mode = CONV_F32 if os.environ.get("KOKOROX_CONV", "") == "f32" else CONV_F16X3
     x, w = _f32(x), _f32(w)
@@ -551,7 +582,7 @@ def conv1d(x, w, bias=None, stride=1, pad=0, dil=1, transposed=False, act=0, slo
 def conv_transpose(x, w, bias=None, stride=6, act=1, slope=0.1, resid=None, up_off=0, mode=1, pre=False, device=0):
     """Polyphase transposed conv as Generator.ups runs it: x [B,Cin,L], w [Cin,Cout,2*stride] -> y [B,Cout,Lout + up_off]
     (+ resid; up_off = 1: output from column 1, column 0 = reflection of column 1)."""
-    lib = load_library()
+    lib = load_test_library()
     x, w = _f32(x), _f32(w)
     B, Cin, L = x.shape
     Cout, k = w.shape[1], w.shape[2]
@@ -568,7 +599,7 @@ def conv1d_epilogue(x, w, bias=None, pad=0, dil=1, resid=None, y_init=None, out_
                     mode=1, device=0):
     """Stride-1 conv through the epilogue forms: y = (conv + bias + resid [+ y_init]) * out_mul / out_div, and the
     fused per-row (sum, sum of squares) when want_stats.  Returns y or (y, stats[B,Cout,2])."""
-    lib = load_library()
+    lib = load_test_library()
     x, w = _f32(x), _f32(w)
     B, Cin, L = x.shape
     Cout, _, k = w.shape
@@ -585,7 +616,7 @@ def conv1d_full(x, w, bias=None, pad=0, dil=1, act=0, slope=0.0, alpha=None, nor
     """Stride-1 conv with the fused input transform (AdaIN affine + leaky / snake) AND the epilogue forms, on a ragged
     batch (lens[b] valid input columns), with pad_ld on the model's padded rows, with flat through the flat list of live
     tiles the model gives the direct-A kernels.  Returns y or (y, stats[B,Cout,2])."""
-    lib = load_library()
+    lib = load_test_library()
     x, w = _f32(x), _f32(w)
     B, Cin, L = x.shape
     Cout, _, k = w.shape
@@ -601,7 +632,7 @@ def conv1d_full(x, w, bias=None, pad=0, dil=1, act=0, slope=0.0, alpha=None, nor
 
 def lstm(x, params, device=0):
     """x [B,L,n_in]; params = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r) -> [B,L,512]."""
-    lib = load_library()
+    lib = load_test_library()
     x = _f32(x)
     B, L, n_in = x.shape
     ps = [_f32(p) for p in params]
@@ -612,7 +643,7 @@ def lstm(x, params, device=0):
 
 def attention(qkv, lens, device=0):
     """qkv [B,2304,T] (rows Q|K|V, 12 heads x 64 each), lens [B] -> ctx [B,768,T] (ALBERT self-attention)."""
-    lib = load_library()
+    lib = load_test_library()
     qkv = _f32(qkv)
     B, C, T = qkv.shape
     assert C == 2304
@@ -624,7 +655,7 @@ def attention(qkv, lens, device=0):
 
 def harmonic_source(f0, lin_w, lin_b, seed=0, utt_base=0, noise_off=False, device=0):
     """f0 [B,2F] -> har_source [B,600F]."""
-    lib = load_library()
+    lib = load_test_library()
     f0 = _f32(f0)
     B, F2 = f0.shape
     lin_w = _f32(np.asarray(lin_w).reshape(-1))

@@ -171,11 +171,14 @@ def test_direct_a_gemm_assembly(tmp_path):
         bad = _audit_no_touch_before_wait(lines)
         assert not bad, f"{name}: ring registers touched before their wait: {bad[:3]}"
         if "dagn_kernel" in name:
-            # the narrow form: every wait of the loop is vmcnt(10) = "the one younger slot", so exactly ten vector loads
-            # (2 weight fragments + 8 input values) must lie between two consecutive waits, and nothing else may load or store
+            # the narrow form, ring of R = 6 slots: every wait of the loop is vmcnt(10 (R - 2)) = "the R - 2 younger slots", so exactly
+            # ten vector loads (2 weight fragments + 8 input values) must lie between two consecutive waits, and nothing else may
+            # load or store; the one wait behind the ring's first fill is vmcnt(10 (R - 1))
             body = [ln.strip() for ln in lines]
-            waits = [i for i, ln in enumerate(body) if ln.startswith("s_waitcnt vmcnt(10)")]
-            assert len(waits) == 3, f"{name}: {len(waits)} ring waits in the unrolled round of three"
+            R = 6
+            assert sum(1 for ln in body if ln.startswith(f"s_waitcnt vmcnt({10 * (R - 1)})")) == 1, f"{name}: the wait behind the first fill"
+            waits = [i for i, ln in enumerate(body) if ln.startswith(f"s_waitcnt vmcnt({10 * (R - 2)})")]
+            assert len(waits) == R, f"{name}: {len(waits)} ring waits in the unrolled round of {R}"
             for a0, a1 in zip(waits, waits[1:]):
                 n = sum(1 for ln in body[a0:a1] if re.match(r"(global|buffer|flat|scratch)_(load|store|atomic)", ln))
                 assert n == 10, f"{name}: {n} vector-memory operations between two ring waits, the waits assume 10"

@@ -147,7 +147,7 @@ def test_lstm_handoff_timeout_fails_the_call_it_belongs_to(blob_path):
     try:
         good = m.infer([list(ids[0])], [list(styles[0])], 1.0, seed=4, flags=hk.KX_FLAG_TAPS)
         good_taps = {n: m.tap(n, 0).copy() for n in names}
-        lib = hk.load_library()
+        lib = hk.load_test_library()
         assert lib.kx_test_lstm_fault(6) != 0, "the fault hook must not arm outside a test process (KX_TEST_HOOKS unset)"
         os.environ["KX_TEST_HOOKS"] = "1"
         assert lib.kx_test_lstm_fault(6) == 0  # the sixth LSTM of a forward = predictor.shared, over the frame axis

@@ -99,6 +99,33 @@ def test_bilstm(L, n_in):
     assert np.abs(y - ref).max() < 1e-5
 
 
+@pytest.mark.gpu
+def test_bilstm_two_and_four_workgroups_give_the_same_bits():
+    """Round 5: batches that leave CUs idle run the resident-weights recurrence on FOUR workgroups per (utterance, direction)
+    (512 threads, all of a lane's weights in registers) instead of two; a lane's arithmetic is the same either way, so the form
+    may depend on the batch: forced to 2 and to 4 on the same input, bit for bit, and against the float64 reference."""
+    from kokorox_amd import hip_koko as hk
+    rng = np.random.default_rng(5)
+    B, L, n_in = 3, 47, 640
+    x = rng.standard_normal((B, L, n_in), dtype=np.float32)
+    lstm = torch.nn.LSTM(n_in, 256, batch_first=True, bidirectional=True).double()
+    ps = [getattr(lstm, n).detach().float().numpy() for n in
+          ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse", "bias_ih_l0_reverse",
+           "bias_hh_l0_reverse")]
+    tlib = hk.load_test_library()
+    try:
+        tlib.kx_test_lstm_parts(2)
+        y2 = hk.lstm(x, ps)
+        tlib.kx_test_lstm_parts(4)
+        y4 = hk.lstm(x, ps)
+    finally:
+        tlib.kx_test_lstm_parts(0)
+    np.testing.assert_array_equal(y2, y4)
+    with torch.no_grad():
+        ref = lstm(torch.from_numpy(x).double())[0].numpy()
+    assert np.abs(y4 - ref).max() < 2e-5
+
+
 def test_bilstm_more_pairs_than_cus():
     """The two-CU recurrence at B = 130: 520 workgroups on 256 CUs, so halves wait for partners that are dispatched
     later (blocks are dispatched in order and every poll is bounded); ragged lengths; no sticky error, f64 parity."""

@@ -81,8 +81,8 @@ def test_mix_styles_matches_reference_rule(tmp_path):
         V.mix_styles(styles, "a+b", 3)
 
 
-def _header_symbols():
-    txt = open(os.path.join(ROOT, "include", "kokorox_hip.h")).read()
+def _header_symbols(name="kokorox_hip.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(kx_[a-z0-9_]+)\s*\(", txt)))
 
@@ -96,6 +96,19 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, n), f"libkokorox_hip.so does not export {n}"
     assert sorted(hk.ABI_SYMBOLS) == names
     assert b"gfx950" in lib.kx_version()
+
+
+def test_test_hooks_live_in_their_own_library():
+    """The stand-alone kernel hooks (include/kokorox_hip_test.h) are exported by libkokorox_hip_test.so and by it alone: the
+    production library ships none of them."""
+    from kokorox_amd import hip_koko as hk
+    lib, tlib = hk.load_library(), hk.load_test_library()
+    names = [n for n in _header_symbols("kokorox_hip_test.h") if n.startswith("kx_test_")]
+    assert sorted(names) == sorted(hk.TEST_ABI_SYMBOLS) and len(names) >= 8
+    for n in names:
+        assert hasattr(tlib, n), f"libkokorox_hip_test.so does not export {n}"
+        assert not hasattr(lib, n), f"libkokorox_hip.so exports the test hook {n}"
+    assert not [n for n in _header_symbols() if n.startswith("kx_test_")]
 
 
 def _split_args(arglist: str):
