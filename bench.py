@@ -645,17 +645,29 @@ def main():
         f1 = torch.zeros(1, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
 
+        host_ms = []  # host-side milestones of every timed call (kx_call_times) + the moment kx_infer_device returned
+
         def one():
             t = time.perf_counter()
             model.infer_device(ids1.data_ptr(), T, lens1, st1.data_ptr(), speeds, a1.data_ptr(), audio_ld, f1.data_ptr(), seed=2)
+            t_ret = time.perf_counter() - t
             model.sync()
-            return time.perf_counter() - t
+            dt = time.perf_counter() - t
+            host_ms.append(model.call_times() + [t_ret * 1e3])
+            return dt
 
         for _ in range(5):
             one()
+        host_ms.clear()
         ts = np.sort(np.array([one() for _ in range(a.latency_b1)]))
+        hm = np.median(np.array(host_ms), axis=0)
         lat_b1 = {"calls": int(len(ts)), "median_ms": float(ts[len(ts) // 2] * 1e3), "p99_ms": float(ts[min(len(ts) - 1, int(len(ts) * 0.99))] * 1e3),
                   "min_ms": float(ts[0] * 1e3), "rtf_at_median": F * 600 / 24000.0 / float(ts[len(ts) // 2]),
+                  # where a call's wall time goes on the host (medians, ms from the call's entry): the front half is queued, the GPU
+                  # has finished it (the one host wait: predicted frame counts size the back half), the back half is planned, the
+                  # back half is queued = kx_infer_device returns; the rest of the latency is kx_sync waiting for the GPU
+                  "host_ms": {"front_queued": float(hm[0]), "front_done": float(hm[1]), "back_planned": float(hm[2]),
+                              "back_queued": float(hm[3]), "infer_device_returned": float(hm[4])},
                   "workload": f"batch 1, one {a.phonemes}-phoneme utterance (T={T}), durations pinned 3,3,3,4 -> F={F} "
                               f"({F * 600 / 24000.0:.2f} s of audio), inputs in HBM, kx_infer_device + kx_sync per call"}
         progress(f"batch-1 latency: median {lat_b1['median_ms']:.2f} ms, p99 {lat_b1['p99_ms']:.2f} ms")

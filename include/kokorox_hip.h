@@ -138,6 +138,11 @@ int kx_set_pinned_durations(kx_model* m, const int32_t* pattern, int n);
  * stream sync + hipFree + hipMalloc of gigabytes, measured as a 1.3 s latency outlier the first time a larger batch shape
  * arrives.  No reference counterpart (ONNX Runtime allocates per run).  A pinned pattern set before stays in force. */
 int kx_warmup(kx_model* m, int B, int n_tokens, int frames_per_token);
+/* Host-side milestones of the last kx_infer_device / kx_infer* call on this model, in ms from the call's entry:
+ * out4[0] front half queued, [1] front half finished on the GPU (the forward's one host wait: the predicted frame counts size
+ * everything downstream), [2] back half planned, [3] back half queued (kx_infer_device returns here, the GPU still running). */
+int kx_call_times(kx_model* m, double* out4);
+
 /* Capacities in bytes of the three device arenas (token axis, frame axis, I/O): they change only when a larger shape arrives. */
 int kx_arena_bytes(kx_model* m, int64_t* out3);
 

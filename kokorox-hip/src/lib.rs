@@ -62,6 +62,7 @@ extern "C" {
     fn kx_sync(m: *mut KxModel) -> c_int;
     fn kx_warmup(m: *mut KxModel, b: c_int, n_tokens: c_int, frames_per_token: c_int) -> c_int;
     fn kx_arena_bytes(m: *mut KxModel, out3: *mut i64) -> c_int;
+    fn kx_call_times(m: *mut KxModel, out4: *mut f64) -> c_int;
     fn kx_set_pinned_durations(m: *mut KxModel, pattern: *const i32, n: c_int) -> c_int;
     fn kx_set_conv_mode(m: *mut KxModel, mode: c_int) -> c_int;
     fn kx_get_conv_mode(m: *mut KxModel) -> c_int;

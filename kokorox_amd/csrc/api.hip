@@ -228,6 +228,13 @@ int kx_warmup(kx_model* m, int B, int n_tokens, int frames_per_token) {
     return guarded(m, [&](Model& M) { M.warmup(B, n_tokens, frames_per_token); });
 }
 
+int kx_call_times(kx_model* m, double* out4) {
+    return guarded(m, [&](Model& M) {
+        KX_REQUIRE(out4, "call_times: null argument");
+        M.call_times(out4);
+    });
+}
+
 int kx_arena_bytes(kx_model* m, int64_t* out3) {
     if (!out3) return KX_ERR_INVALID;
     return guarded(m, [&](Model& M) { M.arena_bytes(out3); });

@@ -1166,6 +1166,11 @@ void launch_conv1d_f16x3_da_pre(const ConvArgs& a, int B, int max_cols, hipStrea
     KX_REQUIRE(bn == 256 || bn == 128, "conv1d f16x3 da pre: tile of 256 or 128 columns");
     // the chunk term of the image offsets is a 32-bit scalar: n_chunks x four planes x x16_ld x 16 B per utterance
     KX_REQUIRE((long)a.n_chunks16 * 64 * a.x16_ld < (1L << 31), "conv1d f16x3 da pre: image of one utterance beyond 2 GiB");
+    // small grids (the 128-column tile was chosen): the narrow form without staging, 32 rows x 128 columns per workgroup
+    if (bn == 128 && conv16_dapn_eligible(a)) {
+        launch_conv1d_f16x3_dapn(a, B, max_cols, s);
+        return;
+    }
     const bool w64 = a.K == 3 && (a.K - 1) * a.dil <= 64;  // the unrolled 3-tap forms (W2 on the 256-column tile); else run-time taps
     if (bn == 256) {
         if (w64) launch_da_inst<ACT_NONE, 3, 8, true, true>(a, B, max_cols, s);

@@ -934,20 +934,42 @@ void launch_pool_up2(const float* x, long xbs, int xld, int C, const float* mean
 // the x300 linear up-sampling  src = fma(1/300, j+0.5, -0.5);  out = fma(l0, p0, l1*p1).
 // Phases reach ~1e5 rad, where one float32 ulp is ~0.008 rad, so any other operation order
 // decorrelates the harmonics ("Parity").
-__global__ void source_phase_kernel(const float* f0, long f0_bs, const int* frames, float* phase, int L2max) {
-    const int b = blockIdx.x, h = threadIdx.x;
-    if (h >= 9) return;
+// Three passes per block of SRC_CH steps (round 5): the per-step terms rad for all nine harmonics in parallel, then the running sums
+// by nine lanes -- the ONLY sequential part: one f64 add per step, in step order, exactly the chain of the one-loop form it
+// replaces (201 us for 844 steps at batch 1: fmodf, a division and a global load inside the dependent loop) -- then the scaling
+// in parallel.  Same operations on the same values in the same order: same bits.
+constexpr int SRC_CH = 1024;
+__global__ __launch_bounds__(256) void source_phase_kernel(const float* f0, long f0_bs, const int* frames, float* phase, int L2max) {
+    __shared__ float buf[9][SRC_CH + 1];  // (+ 1: the nine lanes of the second pass walk nine rows side by side)
+    const int b = blockIdx.x, tid = threadIdx.x;
     const int n2 = 2 * frames[b];
-    const float hm = (float)(h + 1);
-    double cs = 0.0;
-    float* out = phase + ((long)b * 9 + h) * L2max;
-    for (int i = 0; i < n2; ++i) {
-        const float fn = __fmul_rn(f0[b * f0_bs + i], hm);
-        float rad = fmodf(__fdiv_rn(fn, 24000.0f), 1.0f);
-        if (rad < 0.f) rad = __fadd_rn(rad, 1.0f);
-        cs += (double)rad;
-        const float c32 = (float)cs;
-        out[i] = __fmul_rn(__fmul_rn(__fmul_rn(c32, 2.0f), 3.14159274101257324f), 300.0f);
+    double cs = 0.0;  // (lanes 0 .. 8: the running sum of harmonic tid)
+    for (int base = 0; base < n2; base += SRC_CH) {
+        const int n = n2 - base < SRC_CH ? n2 - base : SRC_CH;
+        for (int i = tid; i < n; i += 256) {
+            const float f = f0[b * f0_bs + base + i];
+#pragma unroll
+            for (int h = 0; h < 9; ++h) {
+                const float fn = __fmul_rn(f, (float)(h + 1));
+                float rad = fmodf(__fdiv_rn(fn, 24000.0f), 1.0f);
+                if (rad < 0.f) rad = __fadd_rn(rad, 1.0f);
+                buf[h][i] = rad;
+            }
+        }
+        __syncthreads();
+        if (tid < 9) {
+            for (int i = 0; i < n; ++i) {
+                cs += (double)buf[tid][i];
+                buf[tid][i] = (float)cs;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+#pragma unroll
+            for (int h = 0; h < 9; ++h)
+                phase[((long)b * 9 + h) * L2max + base + i] = __fmul_rn(__fmul_rn(__fmul_rn(buf[h][i], 2.0f), 3.14159274101257324f), 300.0f);
+        }
+        __syncthreads();
     }
 }
 
@@ -1014,7 +1036,7 @@ void launch_source(const float* f0, long f0_bs, const int* frames, int B, int Fm
                    const float* lin_b, uint64_t seed, uint64_t utt_base, const uint64_t* utt_seeds, int noise_off,
                    float* phase_ws, float* har, long har_bs, hipStream_t s) {
     const int L2max = 2 * Fmax;
-    hipLaunchKernelGGL(source_phase_kernel, dim3(B), dim3(64), 0, s, f0, f0_bs, frames, phase_ws, L2max);
+    hipLaunchKernelGGL(source_phase_kernel, dim3(B), dim3(256), 0, s, f0, f0_bs, frames, phase_ws, L2max);
     KX_HIP(hipGetLastError());
     hipLaunchKernelGGL(source_sample_kernel, dim3((600 * Fmax + 255) / 256, B), dim3(256), 0, s, f0, f0_bs, frames,
                        phase_ws, L2max, lin_w, lin_b, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32),

@@ -141,6 +141,9 @@ struct ConvArgs {
 bool conv16_pre_shape(int BM, int rows, int K, int dil, int stride, int act, int in_up2);  // which layers get one: by shape alone
 size_t conv16_pre_image_bytes(int Cin, int x_ld);  // per utterance
 // writes the image of a.x (a's norm parameters, activation, slope, pre-scale) for B utterances of at most Lmax columns
+// the narrow pre-split form for small grids (conv_f16x3_dapn.hip): 32 rows x 128 columns per workgroup, B fragments straight from the image
+bool conv16_dapn_eligible(const ConvArgs& a);
+void launch_conv1d_f16x3_dapn(const ConvArgs& a, int B, int max_cols, hipStream_t s);
 void launch_split_image(const ConvArgs& a, int B, int Lmax, void* img, long img_bs, hipStream_t s);
 
 // tile_prefix of a LenMap for `bn`-column tiles (+ `extra` columns per utterance: the polyphase convs' L + 1), on the device

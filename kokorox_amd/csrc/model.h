@@ -133,6 +133,9 @@ class Model {
     // the pooled page-locked buffer and the flat tile tables for that shape before the first real request
     void warmup(int B, int n_tokens, int frames_per_token);
     void arena_bytes(int64_t out[3]) const { out[0] = (int64_t)arenaT_.cap; out[1] = (int64_t)arenaF_.cap; out[2] = (int64_t)arenaIO_.cap; }
+    // host-side milestones of the last infer_device call, ms from its entry: front half queued, front half done on the GPU (the
+    // one host wait), back half planned, back half queued (= the call's return)
+    void call_times(double out[4]) const { for (int i = 0; i < 4; ++i) out[i] = call_ms_[i]; }
     void profile_enable(bool on);
     void profile_read(int64_t* launches, double* ms, double* flops);
     struct ProfRec { int rows, Cin, K, dil, stride, store; double cols, flops; float ms; double bytes; };
@@ -261,6 +264,7 @@ class Model {
     struct PartInfo { const float2* part; int tiles, cols_per_tile, C; };
     std::map<const float*, PartInfo> parts_;  // output tensor -> fused statistics partials of its producer
 
+    double call_ms_[4] = {0, 0, 0, 0};
     bool diag_on_ = false;
     std::vector<DiagRec> diag_recs_;
     float* d_diag_ = nullptr;  // [diag_cap_][3]

@@ -1,6 +1,7 @@
 // Host side of the MI355X Kokoro-82M forward: weight registry + repacking, arenas and the
 // launch sequence that replaces `sess.run` (kokorox/src/onn/ort_koko.rs:79).  The graph is
 // the published Kokoro-82M; stage comments name the upstream module.
+#include <chrono>
 #include "model.h"
 
 #include <sys/stat.h>
@@ -1084,6 +1085,10 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     }
     for (int i = 0; i < n_speed; ++i) KX_REQUIRE(speeds_host[i] > 0.f, "infer: speed must be > 0");
     KX_HIP(hipSetDevice(device));
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t_enter = clk::now();
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    for (double& v : call_ms_) v = 0.0;
     DeviceTurn turn(*this);  // (until this call has queued its last launch)
     B_ = B;
     Tmax_ = Tmax;
@@ -1265,7 +1270,9 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
 
     // ===== the one host round trip: predicted frame counts size everything downstream =========
     KX_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));  // the TextEncoder branch joins here
+    call_ms_[0] = ms_since(t_enter);  // host time to queue the front half
     KX_HIP(hipStreamSynchronize(stream_));
+    call_ms_[1] = ms_since(t_enter);  // ... until the GPU has finished it (the forward's one host wait)
     check_dev_err();
     if (h_bad_id_) {  // a device-side id outside the embedding tables (clamped for the gather, never read out of bounds)
         const unsigned w = h_bad_id_ - 1;
@@ -1480,12 +1487,14 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     arenaF_.measure = false;
     const size_t needF = arenaF_.off;
     ensure_arena(arenaF_, needF);
+    call_ms_[2] = ms_since(t_enter);  // ... until the back half is planned (dry run of the launch sequence)
     try {
         back(arenaF_);
     } catch (...) {
         sync_lanes();  // (nothing of this call may still be running on a side lane when the arenas are handed out again)
         throw;
     }
+    call_ms_[3] = ms_since(t_enter);  // ... until the back half is queued (the call returns; the GPU is still running it)
 }
 
 // page-locked scratch for the small per-call host arrays (grown when a larger batch arrives; the stream is idle then: a

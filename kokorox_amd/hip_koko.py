@@ -73,6 +73,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_import_onnx": (i32, [cp, cp, cp, sz]),
         "kx_warmup": (i32, [vp, i32, i32, i32]),
         "kx_arena_bytes": (i32, [vp, C.POINTER(i64)]),
+        "kx_call_times": (i32, [vp, C.POINTER(C.c_double)]),
         "kx_create_from_device_blob": (vp, [vp, sz, i32, cp, sz]),
         "kx_destroy": (None, [vp]),
         "kx_last_error": (cp, [vp]),
@@ -165,7 +166,7 @@ TEST_ABI_SYMBOLS = ["kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test
 ABI_SYMBOLS = [
     "kx_version", "kx_init", "kx_create", "kx_import_onnx", "kx_create_from_device_blob", "kx_create_replicas", "kx_destroy",
     "kx_last_error", "kx_last_error_copy", "kx_infer",
-    "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_warmup", "kx_arena_bytes", "kx_set_utterance_base", "kx_set_lanes",
+    "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_warmup", "kx_arena_bytes", "kx_call_times", "kx_set_utterance_base", "kx_set_lanes",
     "kx_set_conv_mode", "kx_get_conv_mode", "kx_set_stft_variant", "kx_get_stft_variant",
     "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_profile_aux", "kx_diag_enable", "kx_diag_count", "kx_diag_get", "kx_set_act_prescale", "kx_set_voice_table", "kx_infer_voices",
     "kx_infer_packed", "kx_free_packed", "kx_dispatcher_create", "kx_dispatcher_submit", "kx_dispatcher_submit_ex", "kx_dispatcher_model_batches",
@@ -359,6 +360,12 @@ class HipKoko:
     def arena_bytes(self):
         out = (C.c_int64 * 3)()
         self._check(self._lib.kx_arena_bytes(self._h, out))
+        return list(out)
+
+    def call_times(self):
+        """Host milestones of the last call in ms from its entry: [front queued, front done (the host wait), back planned, back queued]."""
+        out = (C.c_double * 4)()
+        self._check(self._lib.kx_call_times(self._h, out))
         return list(out)
 
     def set_conv_mode(self, mode: int):
