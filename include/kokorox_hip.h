@@ -99,7 +99,7 @@ int kx_last_error_copy(const kx_model* m, char* buf, size_t buf_len);
  *   speeds   [n_speed] float32, n_speed = 1 (shared, ort_koko.rs:67-68) or B
  *   seed     Philox key of the harmonic-source noise; utterance b of the call draws the
  *            stream (seed, utt_base + b)
- *   out      *out = malloc'd float32 buffer holding the B waveforms back to back;
+ *   out      *out = a library-owned (pooled, page-locked) float32 buffer holding the B waveforms back to back;
  *            out_lens[b] = samples of utterance b (600 * predicted frames).  Free with
  *            kx_free_audio.  The reference likewise returns an owned copy
  *            (ort_koko.rs:85 `data.to_vec()`).
@@ -119,13 +119,29 @@ void kx_free_audio(float* p);
  * length is then in *need_ld), or if a token id in d_ids lies outside 0..177: device-side ids are range-checked by
  * the embedding kernels (clamped for the gather, so nothing is read out of bounds) and reported at the call's one
  * host synchronisation point.  The call returns after the work has been queued on the
- * model's stream and its frame counts are known; kx_sync waits for completion. */
+ * model's stream and its frame counts are known; kx_sync waits for completion.
+ * Streams: the model's streams are NON-BLOCKING (they do not synchronise with the legacy null stream).  The call orders
+ * itself against the NULL stream on both sides, on the GPU, without a host stall: its reads of d_ids / d_styles wait for what
+ * the caller had queued on the null stream before the call, and null-stream work queued AFTER the call returns (torch's default
+ * stream reading d_audio / d_frames, or writing the next request into d_ids / d_styles) waits for the end of this forward.
+ * A caller that produces the inputs or consumes the outputs on any OTHER stream (a torch side stream, a per-thread default
+ * stream) is not ordered at all: it must finish its writes before the call and call kx_sync before touching d_audio,
+ * d_frames, d_ids or d_styles again. */
 int kx_infer_device(kx_model* m, const int64_t* d_ids, int64_t t_stride, const int32_t* lens_host,
                     int B, const float* d_styles, const float* speeds_host, int n_speed,
                     uint64_t seed, uint32_t flags, float* d_audio, int64_t audio_ld,
                     int32_t* d_frames, int64_t* need_ld);
 
 int kx_sync(kx_model* m);
+
+/* What the model's LSTM recurrences are running on, and whether anything went wrong (SURVEY 8b "Threading"; the reference has
+ * nothing to report: one Mutex<Session>, ort_koko.rs:78).  out4[0]: 0 = the resident-weights forms (two / four workgroups per
+ * utterance and direction, which hand h over between CUs), 1 = the streaming fall-back (one workgroup, no hand-off); out4[1]:
+ * hand-off time-outs so far (a part of a recurrence starved behind other work on the GPU for ~0.1 s); out4[2]: clean forwards
+ * left until the resident forms return (64 after a time-out, 0 in normal operation); out4[3]: calls that were re-run
+ * transparently after a time-out.  Both forms give the SAME BITS, so the switch never changes a result; it costs time
+ * (~6 us against 1.6 - 2.5 us per recurrence step).  All zeros in a healthy deployment. */
+int kx_model_status(kx_model* m, int64_t* out4);
 
 /* Benchmark control (SURVEY.md §8d "duration pinning"): when set, the predicted duration
  * of token t is replaced by pattern[t % n] for every utterance (the duration head still
@@ -225,7 +241,7 @@ int kx_set_voice_table(kx_model* m, const float* table, int n_voices);
 #define KX_PACK_F32_STEREO 1
 #define KX_PACK_PCM16_MONO 2
 
-/* kx_infer with device-side style lookup/mix and packed output.  *out = malloc'd bytes of the B utterances back
+/* kx_infer with device-side style lookup/mix and packed output.  *out = library-owned bytes of the B utterances back
  * to back (kx_free_packed); out_bytes[b] / out_samples[b] per utterance. */
 int kx_infer_voices(kx_model* m, const int64_t* ids, int64_t t_stride, const int32_t* lens, int B,
                     const int32_t* voice_ids, const float* weights, int max_mix, const float* speeds, int n_speed,
@@ -239,29 +255,32 @@ void kx_free_packed(void* p);
 /* ---- request dispatcher ----------------------------------------------------
  * Replaces the reference's one-request-at-a-time `Mutex<Session>` (kokorox/src/onn/ort_koko.rs:78; callers
  * kokorox-openai/src/lib.rs:370-439, kokorox-websocket/src/lib.rs:657-668).  Any number of threads submit
- * single utterances; one worker per model (= per GPU) coalesces whatever is queued — up to max_batch, waiting
- * at most max_wait_us after the first arrival — into one batched forward.  A request's waveform depends only
- * on (ids, style, speed, seed), not on what it was batched with, nor on which model ran it — with one exception: a model
- * whose two-CU LSTM recurrence ever timed out (a KX_ERR_DEVICE failure naming the LSTM) runs the one-CU recurrence from
- * then on, whose sums are added in another order, so ITS results agree with the other models' to rounding only (and, past
- * the harmonic-phase integration, in form only).
- * A request is checked completely when it is submitted (token ids and count, speed, format, voice ids against the smallest
- * voice table among the models, mix size) and refused there with KX_ERR_INVALID: a bad request never reaches a batch.
- * If a batch still fails as a whole, an INVALID-class failure is re-run request by request (only the requests that fail
- * alone report it) and a DEVICE-class failure is retried once as a batch, then reported by every request of it. */
+ * single utterances; two workers per model (= per GPU; one runs a forward while the other hands the previous batch's results
+ * to its clients) coalesce whatever is queued — up to max_batch, waiting at most max_wait_us after the first arrival — into
+ * one batched forward.  A request's waveform depends only on (ids, style, speed, seed), not on what it was batched with, nor
+ * on which model ran it, nor on which LSTM recurrence that model was running (kx_model_status: both forms give the same bits).
+ * A request is checked completely when it is submitted (token ids against the models' embedding tables, token count, speed,
+ * format, voice ids against the smallest voice table among the models, mix size) and refused there with KX_ERR_INVALID: a bad
+ * request never reaches a batch.  If a batch still fails as a whole, an INVALID-class failure is re-run request by request
+ * (only the requests that fail alone report it); a DEVICE-class failure is retried once as a batch, and if it fails again
+ * that MODEL is marked failed: it takes no more work and its batch goes back to the head of the queue for the healthy models
+ * (kx_dispatcher_health).  Requests report KX_ERR_DEVICE only when no healthy model is left.
+ * Results (*out of the submit calls) are NOT malloc'd memory: they point into a page-locked buffer shared by the requests of
+ * one batch, which returns to the library's pool when the last of them has been released.  Release them with kx_free_audio /
+ * kx_free_packed and with nothing else (free() corrupts the heap); a result that is kept alive keeps its batch's buffer alive. */
 typedef struct kx_dispatcher kx_dispatcher;
 kx_dispatcher* kx_dispatcher_create(kx_model** models, int n_models, int max_batch, int max_wait_us, char* err,
                                     size_t err_len);
-/* Blocking; thread-safe.  ids = n_tokens ids incl. the two 0 pads; style = 256 floats.  *out is malloc'd
- * (free with kx_free_audio).  Equals kx_infer(B = 1, same seed, utterance base 0) bit for bit. */
+/* Blocking; thread-safe.  ids = n_tokens ids incl. the two 0 pads; style = 256 floats.  *out: release with kx_free_audio
+ * only (see above).  Equals kx_infer(B = 1, same seed, utterance base 0) bit for bit. */
 int kx_dispatcher_submit(kx_dispatcher* d, const int64_t* ids, int n_tokens, const float* style, float speed,
                          uint64_t seed, float** out, int64_t* out_len, char* err, size_t err_len);
 /* The request as the reference's servers make it (kokorox-openai/src/lib.rs:370-439, kokorox-websocket/src/lib.rs:
  * 657-736): the voice is EITHER the 256-float style row (`style`, voice_ids = NULL) OR names into the device voice
  * table every model of the dispatcher holds (kx_set_voice_table): `voice_ids[n_mix]` with `weights` = NULL and
  * n_mix = 1 for a single voice (row copy), or with `weights[n_mix]` for a mix "a.4+b.5" (sum_k row_k * (w_k * 0.1),
- * koko.rs:1255-1306; ids < 0 are skipped); `format` is a KX_PACK_* output form.  *out = malloc'd bytes
- * (kx_free_audio); requests of every kind and format share batches, and a request's bytes equal those of
+ * koko.rs:1255-1306; ids < 0 are skipped); `format` is a KX_PACK_* output form.  *out = the packed bytes (release with
+ * kx_free_audio / kx_free_packed only); requests of every kind and format share batches, and a request's bytes equal those of
  * kx_infer_voices / kx_infer_packed (B = 1, same seed, utterance base 0) whatever it was batched with.
  * Errors are per request: when a batch fails as a whole its requests are re-run one by one. */
 int kx_dispatcher_submit_ex(kx_dispatcher* d, const int64_t* ids, int n_tokens, const float* style,
@@ -271,9 +290,12 @@ int kx_dispatcher_stats(kx_dispatcher* d, int64_t* n_requests, int64_t* n_batche
 /* batches each model (worker) has run so far: per_model[n_models] */
 int kx_dispatcher_model_batches(kx_dispatcher* d, int64_t* per_model, int n_models);
 /* What went wrong so far: requests that were re-run one by one after their batch failed with an INVALID-class error, and
- * batches that were run a second time after a DEVICE-class failure (a recurrence hand-off time-out: that model then runs the
- * one-CU recurrence).  Both stay 0 in a healthy deployment. */
+ * batches that were run a second time after a DEVICE-class failure.  Both stay 0 in a healthy deployment. */
 int kx_dispatcher_failures(kx_dispatcher* d, int64_t* n_replayed, int64_t* n_retried);
+/* Per-model health: healthy[i] = 1 while model i takes work, 0 once a batch failed on it with KX_ERR_DEVICE twice in a row (it
+ * is then out for the dispatcher's lifetime: destroy the dispatcher and the model to recover the GPU); *n_model_failures =
+ * models marked failed so far, *n_requeued = requests that went back to the queue for another model (either may be NULL). */
+int kx_dispatcher_health(kx_dispatcher* d, int32_t* healthy, int n_models, int64_t* n_model_failures, int64_t* n_requeued);
 void kx_dispatcher_destroy(kx_dispatcher* d);  /* waits for queued requests; models stay alive */
 
 /* ---- debugging ---------------------------------------------------------------------

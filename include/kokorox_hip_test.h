@@ -69,8 +69,9 @@ int kx_test_source(int device_id, const float* f0, int B, int F2, const float* l
  * Arms only in a process whose environment has KX_TEST_HOOKS=1 (KX_ERR_STATE otherwise). */
 int kx_test_lstm_fault(int nth);
 
-/* Workgroups per (utterance, direction) of the resident-weights LSTM recurrence (process-wide, test only): 2 or 4 whatever the
- * batch, 0 = by batch size (four while 8 B workgroups fit the CUs).  Both forms give the same bits. */
+/* Workgroups per (utterance, direction) of the LSTM recurrence (process-wide, test only): 2 or 4 = that resident-weights form
+ * whatever the batch, 1 = the streaming fall-back (one workgroup), 0 = by batch size (four while 8 B workgroups fit the CUs).
+ * All three give the same bits. */
 int kx_test_lstm_parts(int n);
 
 #ifdef __cplusplus

@@ -63,6 +63,7 @@ extern "C" {
     fn kx_warmup(m: *mut KxModel, b: c_int, n_tokens: c_int, frames_per_token: c_int) -> c_int;
     fn kx_arena_bytes(m: *mut KxModel, out3: *mut i64) -> c_int;
     fn kx_call_times(m: *mut KxModel, out4: *mut f64) -> c_int;
+    fn kx_model_status(m: *mut KxModel, out4: *mut i64) -> c_int;
     fn kx_set_pinned_durations(m: *mut KxModel, pattern: *const i32, n: c_int) -> c_int;
     fn kx_set_conv_mode(m: *mut KxModel, mode: c_int) -> c_int;
     fn kx_get_conv_mode(m: *mut KxModel) -> c_int;
@@ -100,6 +101,8 @@ extern "C" {
                            max_batch_seen: *mut i64) -> c_int;
     fn kx_dispatcher_failures(d: *mut KxDispatcher, n_replayed: *mut i64, n_retried: *mut i64) -> c_int;
     fn kx_dispatcher_model_batches(d: *mut KxDispatcher, per_model: *mut i64, n_models: c_int) -> c_int;
+    fn kx_dispatcher_health(d: *mut KxDispatcher, healthy: *mut i32, n_models: c_int, n_model_failures: *mut i64,
+                            n_requeued: *mut i64) -> c_int;
     fn kx_dispatcher_destroy(d: *mut KxDispatcher);
     fn kx_version() -> *const c_char;
 }

@@ -211,13 +211,33 @@ int kx_infer_device(kx_model* m, const int64_t* d_ids, int64_t t_stride, const i
                     float* d_audio, int64_t audio_ld, int32_t* d_frames, int64_t* need_ld) {
     return guarded(m, [&](Model& M) {
         M.order_after_null_stream();  // (the caller's device inputs: typically written on the legacy null stream)
-        M.infer_device(d_ids, t_stride, lens_host, B, d_styles, speeds_host, n_speed, seed, flags, d_audio, audio_ld,
-                       d_frames, need_ld);
+        try {
+            M.infer_device(d_ids, t_stride, lens_host, B, d_styles, speeds_host, n_speed, seed, flags, d_audio, audio_ld,
+                           d_frames, need_ld);
+        } catch (const kx::LstmTimeout&) {
+            // a token-axis recurrence timed out (seen at the forward's one host wait): the inputs are still where the caller put
+            // them, so the call is simply made again, now on the streaming recurrence (same bits).  A time-out of the frame-axis
+            // recurrence shows only at kx_sync, which then fails with KX_ERR_DEVICE: that call cannot be repeated from here.
+            M.note_rerun();
+            M.infer_device(d_ids, t_stride, lens_host, B, d_styles, speeds_host, n_speed, seed, flags, d_audio, audio_ld,
+                           d_frames, need_ld);
+        }
+        M.order_null_stream_after();  // (the caller's later null-stream work waits, on the GPU, for the forward's end)
     });
 }
 
 int kx_sync(kx_model* m) {
-    return guarded(m, [&](Model& M) { M.sync(); });
+    return guarded(m, [&](Model& M) {
+        M.sync();
+        M.note_clean_forward();
+    });
+}
+
+int kx_model_status(kx_model* m, int64_t* out4) {
+    return guarded(m, [&](Model& M) {
+        KX_REQUIRE(out4, "model_status: null argument");
+        M.status(out4);
+    });
 }
 
 int kx_set_pinned_durations(kx_model* m, const int32_t* pattern, int n) {

@@ -19,6 +19,8 @@ struct ModelBackend {
         std::vector<int64_t> bytes, samples;
     };
     static int n_voices(kx_model* h) { return h->m->n_voices(); }
+    static int n_vocab(kx_model* h) { return h->m->n_vocab(); }
+    static void free_out(void* p) { kx::host_out_free(p); }
     static int forward(kx_model* h, std::vector<Request*>& batch, Out& o) {
         const int B = (int)batch.size();
         size_t stride = 0;
@@ -169,6 +171,15 @@ int kx_dispatcher_failures(kx_dispatcher* d, int64_t* n_replayed, int64_t* n_ret
     std::lock_guard<std::mutex> lk(d->mu);
     if (n_replayed) *n_replayed = d->n_replayed;
     if (n_retried) *n_retried = d->n_retried;
+    return KX_OK;
+}
+
+int kx_dispatcher_health(kx_dispatcher* d, int32_t* healthy, int n_models, int64_t* n_model_failures, int64_t* n_requeued) {
+    if (!d || n_models < 0 || (n_models > 0 && !healthy)) return KX_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(d->mu);
+    for (int i = 0; i < n_models && i < (int)d->failed.size(); ++i) healthy[i] = d->failed[(size_t)i] ? 0 : 1;
+    if (n_model_failures) *n_model_failures = d->n_model_failures;
+    if (n_requeued) *n_requeued = d->n_requeued;
     return KX_OK;
 }
 

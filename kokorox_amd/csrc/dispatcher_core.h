@@ -20,8 +20,14 @@
 //     smallest voice table of the models, mix size): a bad request is refused there and never reaches a batch, so one
 //     client cannot make other clients' batch fail.
 //   * if a batch still fails as a whole: an INVALID-class failure is re-run request by request and only the requests that
-//     fail alone report it; a DEVICE-class failure (HIP error, recurrence hand-off time-out) is retried ONCE as a batch —
-//     never B times on a GPU that may be faulted — and if it fails again every request of the batch reports it.
+//     fail alone report it; a DEVICE-class failure (HIP error) is retried ONCE as a batch — never B times on a GPU that may
+//     be faulted.  If it fails again the MODEL is marked failed (round 5): its workers stop taking requests, it no longer
+//     counts as a free model, and the batch goes back to the head of the queue for the healthy models; a sticky fault on
+//     one GPU of eight therefore costs its clients one retry, not a share of all traffic failing twice for ever.  Only when
+//     no healthy model is left do requests report the failure (what is queued then, and every later submit).
+//     kx_dispatcher_health / kx_dispatcher_failures show the state.
+//   * a finished request wakes ITS client only (one condition variable per request, signalled under the queue's mutex):
+//     with one shared condition variable every batch woke every waiting client of every model.
 //
 //   * two worker threads per model alternate, so that the host side of a finished batch (handing every client its bytes,
 //     waking it) runs beside the NEXT batch's forward; a worker takes requests only when its model's GPU phase is free,
@@ -33,6 +39,8 @@
 //                                                                         (and Out on success), returns the batch's status
 //   static void distribute(std::vector<dispatch::Request*>&, Out&);       gives every request its out / out_bytes / out_samples
 //   static int n_voices(Handle*);                                         rows of the model's voice table (0 = none)
+//   static int n_vocab(Handle*);                                          rows of its embedding tables (token ids are 0 .. n_vocab - 1)
+//   static void free_out(void*);                                          releases a request's `out` (what distribute handed out)
 #pragma once
 #include <chrono>
 #include <condition_variable>
@@ -69,6 +77,7 @@ struct Request {
     int rc = -1;
     std::string err;
     bool done = false;
+    std::condition_variable cv;  // signalled (under the core's mutex) when `done` is set: wakes this request's client only
     std::chrono::steady_clock::time_point t_submit;
 };
 
@@ -79,11 +88,13 @@ struct Core {
     int max_batch = 64;
     int max_wait_us = 2000;
     std::mutex mu;
-    std::condition_variable cv_work, cv_done, cv_quiet;
+    std::condition_variable cv_work, cv_quiet;
     std::deque<Request*> queue;
     bool stop = false;
     static constexpr int WORKERS_PER_MODEL = 2;
     std::vector<char> busy;  // per model: a forward is running (its GPU phase); 0 = a worker may start the next batch
+    std::vector<char> failed;  // per model: a batch failed with DEVICE twice in a row: the model takes no more work
+    int64_t n_model_failures = 0, n_requeued = 0;
     int inside = 0;  // client threads inside submit() (shutdown waits for them before the object goes away)
     std::vector<std::thread> workers;
     int64_t n_requests = 0, n_batches = 0, max_seen_batch = 0, n_replayed = 0, n_retried = 0;
@@ -92,6 +103,7 @@ struct Core {
     Core(Handle** ms, int n, int max_b, int wait_us) : models(ms, ms + n), max_batch(max_b), max_wait_us(wait_us) {
         per_model_batches.assign((size_t)n, 0);
         busy.assign((size_t)n, 0);
+        failed.assign((size_t)n, 0);
         for (int i = 0; i < n * WORKERS_PER_MODEL; ++i) workers.emplace_back([this, i] { worker(i); });
     }
     Core(const Core&) = delete;
@@ -125,12 +137,13 @@ struct Core {
                 std::unique_lock<std::mutex> lk(mu);
                 for (;;) {
                     // (after `stop` the queue is still drained: a worker leaves only when nothing is waiting)
-                    cv_work.wait(lk, [&] { return (stop && queue.empty()) || (!queue.empty() && !busy[m]); });
+                    cv_work.wait(lk, [&] { return failed[m] || (stop && queue.empty()) || (!queue.empty() && !busy[m]); });
+                    if (failed[m]) return;  // (its sibling marked the model failed: nothing more runs on it)
                     if (queue.empty()) return;
                     // work is here and this model is free: give others a short chance to join, unless every free model
                     // already has a full batch waiting
                     bool go = true;
-                    while (!stop && !queue.empty() && !busy[m] && (long)queue.size() < (long)max_batch * free_models()) {
+                    while (!stop && !failed[m] && !queue.empty() && !busy[m] && (long)queue.size() < (long)max_batch * free_models()) {
                         const auto deadline = queue.front()->t_submit + std::chrono::microseconds(max_wait_us);
                         const auto now = std::chrono::steady_clock::now();
                         if (now >= deadline) break;
@@ -142,6 +155,7 @@ struct Core {
                         cv_work.wait_until(lk, deadline);
 #endif
                     }
+                    if (failed[m]) return;
                     if (queue.empty() || busy[m]) go = false;  // (the sibling worker, or another model's, was quicker)
                     if (go) break;
                 }
@@ -172,29 +186,60 @@ struct Core {
                     if (forward_retrying(h, one, o1) == KX_OK) Backend::distribute(one, o1);
                 }
             }
+            bool model_failed = false, requeued = false;
             {
                 std::lock_guard<std::mutex> lk(mu);
                 busy[m] = false;  // the model's GPU phase is over: its other worker may start the next batch
                 if (replay) n_replayed += (int64_t)batch.size();
+                if (rc == KX_ERR_DEVICE) {
+                    // failed, retried, failed again: the model is out.  Its batch goes back to the HEAD of the queue (in order)
+                    // for the healthy models; with none left, it and everything queued report the failure.
+                    model_failed = true;
+                    if (!failed[m]) n_model_failures += 1;
+                    failed[m] = 1;
+                    if (healthy_models() > 0) {
+                        for (auto it = batch.rbegin(); it != batch.rend(); ++it) queue.push_front(*it);
+                        n_requeued += (int64_t)batch.size();
+                        requeued = true;
+                    } else {
+                        for (Request* r : queue) {
+                            r->rc = KX_ERR_DEVICE;
+                            r->err = "dispatcher: no healthy model is left (" + batch[0]->err + ")";
+                            finish(r);
+                        }
+                        queue.clear();
+                    }
+                }
             }
             cv_work.notify_all();
             if (rc == KX_OK) Backend::distribute(batch, out);  // host work, beside the next batch's forward
-            {
+            if (!requeued) {
                 std::lock_guard<std::mutex> lk(mu);
-                for (Request* r : batch) r->done = true;
+                for (Request* r : batch) finish(r);
             }
-            cv_done.notify_all();
+            if (model_failed) return;
         }
     }
 
+    // (under mu) the request is complete: wake its client.  Signalled while the mutex is held: the client cannot leave submit()
+    // -- and destroy the request with its condition variable -- before this thread has let go of the mutex.
+    void finish(Request* r) {
+        r->done = true;
+        r->cv.notify_one();
+    }
+
+    long healthy_models() const {  // (under mu)
+        long n = 0;
+        for (char f : failed) n += f ? 0 : 1;
+        return n;
+    }
     long free_models() const {  // (under mu) at least 1: the caller's own model is free when this is asked
         long n = 0;
-        for (char b : busy) n += b ? 0 : 1;
+        for (size_t i = 0; i < busy.size(); ++i) n += (busy[i] || failed[i]) ? 0 : 1;
         return n > 0 ? n : 1;
     }
 
-    // One forward; a DEVICE-class failure gets one more try as the same batch (a hand-off time-out switches the model to its
-    // fall-back recurrence); a second failure is what every request of the batch reports.
+    // One forward; a DEVICE-class failure gets one more try as the same batch; a second failure marks the model failed (worker).
     int forward_retrying(Handle* h, std::vector<Request*>& batch, typename Backend::Out& out) {
         int rc = Backend::forward(h, batch, out);
         if (rc != KX_ERR_DEVICE) return rc;
@@ -213,15 +258,19 @@ struct Core {
                 if (err && err_len) snprintf(err, err_len, "dispatcher is shutting down");
                 return KX_ERR_STATE;
             }
+            if (healthy_models() == 0) {
+                if (err && err_len) snprintf(err, err_len, "dispatcher: no healthy model is left (kx_dispatcher_health)");
+                return KX_ERR_DEVICE;
+            }
             ++inside;
             queue.push_back(&r);
             cv_work.notify_all();
-            cv_done.wait(lk, [&] { return r.done; });
+            r.cv.wait(lk, [&] { return r.done; });
             if (--inside == 0) cv_quiet.notify_all();
         }
         if (r.rc != KX_OK) {
             if (err && err_len) snprintf(err, err_len, "%s", r.err.c_str());
-            free(r.out);
+            if (r.out) Backend::free_out(r.out);  // (never set on a failed request today; were it ever, it is not malloc'd memory)
             return r.rc;
         }
         *out = r.out;
@@ -230,15 +279,26 @@ struct Core {
         return KX_OK;
     }
 
-    static bool check_common(const int64_t* ids, int n_tokens, float speed, int format, const char* who, char* err,
-                             size_t err_len) {
+    // rows of the SMALLEST embedding table among the models: token ids must be valid on whichever model takes the request
+    int vocab_everywhere() {
+        int n = -1;
+        for (Handle* h : models) {
+            const int v = Backend::n_vocab(h);
+            n = (n < 0 || v < n) ? v : n;
+        }
+        return n < 0 ? 0 : n;
+    }
+
+    bool check_common(const int64_t* ids, int n_tokens, float speed, int format, const char* who, char* err,
+                      size_t err_len) {
         if (!ids || n_tokens < 1 || n_tokens > KX_MAX_TOKENS || !(speed > 0.f) || format < 0 || format > 2) {
             if (err && err_len) snprintf(err, err_len, "%s: bad argument (1..512 tokens, speed > 0, format 0..2)", who);
             return false;
         }
+        const int nv = vocab_everywhere();  // (from the models' embedding tables: vocab.rs:5-20 has 178 rows, a checkpoint may differ)
         for (int t = 0; t < n_tokens; ++t)
-            if (ids[t] < 0 || ids[t] >= 178) {
-                if (err && err_len) snprintf(err, err_len, "%s: token id outside 0..177", who);
+            if (ids[t] < 0 || ids[t] >= nv) {
+                if (err && err_len) snprintf(err, err_len, "%s: token id outside 0..%d", who, nv - 1);
                 return false;
             }
         return true;

@@ -612,6 +612,19 @@ __global__ __launch_bounds__(1024) void lstm_kernel(const float* gx, long gx_bs,
         __syncthreads();
     }
 }
+// One unit's cell update from its four gate pre-activations (PyTorch order i, f, g, o); returns h.  ONE definition for every
+// recurrence kernel, with the multiply-add spelled out: left to -ffp-contract the same expression was fused in one kernel and
+// not in another, and the resident-weights forms and their streaming fall-back must agree bit for bit.
+__device__ __forceinline__ float lstm_cell(float pi, float pf, float pg, float po, float& c) {
+    const float ig = 1.0f / (1.0f + expf(-pi));
+    const float fg = 1.0f / (1.0f + expf(-pf));
+    const float gg = tanhf(pg);
+    const float og = 1.0f / (1.0f + expf(-po));
+    const float t = ig * gg;
+    c = __builtin_fmaf(fg, c, t);
+    return og * tanhf(c);
+}
+
 // ---- the same recurrence with W_hh fully resident: two CUs per (utterance, direction) -------------------------------
 // One CU cannot hold the 1 MiB of W_hh (512 KiB of registers + 160 KiB of LDS), which is why lstm_kernel streams 60 % of
 // it from L2 on every step (5.5 us per step, bound by the CU's L1 fill rate).  Here the recurrence of one (utterance,
@@ -732,12 +745,7 @@ __global__ __launch_bounds__(LstmParts<NQ>::THREADS) void lstm_pair_kernel(const
         const unsigned tag = (epoch << 16) | (unsigned)(step + 1);
         const int par = step & 1;
         if (tid < HU) {
-            const float ig = 1.0f / (1.0f + expf(-gates[tid]));
-            const float fg = 1.0f / (1.0f + expf(-gates[HU + tid]));
-            const float gg = tanhf(gates[2 * HU + tid]);
-            const float og = 1.0f / (1.0f + expf(-gates[3 * HU + tid]));
-            c = fg * c + ig * gg;
-            const float hn = og * tanhf(c);
+            const float hn = lstm_cell(gates[tid], gates[HU + tid], gates[2 * HU + tid], gates[3 * HU + tid], c);
             if (step + 1 < L) {  // publish for the partners' next step first: one 8-byte agent-scope store
                 const unsigned long long g8 = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(hn);
                 __hip_atomic_store(slots + par * 256 + hf * HU + tid, g8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -753,7 +761,7 @@ __global__ __launch_bounds__(LstmParts<NQ>::THREADS) void lstm_pair_kernel(const
             for (;;) {
                 g8 = __hip_atomic_load(slots + par * 256 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)(g8 >> 32) == tag) break;
-                if (++spins > spin_limit) {  // (1 << 22 ~ seconds: the partner is not coming)
+                if (++spins > spin_limit) {  // (1 << 19 ~ 0.2 s, far beyond any wait for a CU to free up: the partner is not coming)
                     atomicOr(err, 2u);
                     *abort_flag = 1;
                     g8 = 0;
@@ -768,15 +776,108 @@ __global__ __launch_bounds__(LstmParts<NQ>::THREADS) void lstm_pair_kernel(const
     }
 }
 
+// ---- the fall-back: ONE workgroup per (utterance, direction), most of W_hh streamed from L2 every step -------------------------
+// No partner, no hand-off, nothing to wait for: a workgroup that cannot get a CU yet simply starts later.  It is what a model
+// runs after a hand-off of the resident-weights forms timed out (a recurrence's partner starved behind other work on the GPU;
+// DESIGN.md section 7), and since round 5 it gives the SAME BITS as they do: a lane is (row pair, K quarter) of the two-CU
+// form and walks half 0's rows, then half 1's, with the same order of sums ((q0 + q1) + (q2 + q3) over the quad) and the same
+// cell update -- so a model may switch between the forms at any call without its results changing (lstm_kernel above, whose
+// lanes own whole rows, agrees with them to rounding only; it stays as KX_LSTM_PAIR=0's reference form).
+// Half 0's first 8 pieces (of 16 per row) live in registers, its next 4 in LDS (128 KiB); the other 4 and all of half 1
+// (62 % of the 1 MiB) come from L2 on every step: ~6 us per step against 1.6 - 2.5 us resident.
+constexpr int LSTMS_REG = 16, LSTMS_LDS = 8;  // float4 pieces (2 j + row A / B) of half 0 in registers / in LDS
+__global__ __launch_bounds__(1024) void lstm_stream_kernel(const float* gx, long gx_bs, int gx_ld, const float* whhT, float* y,
+                                                           long y_bs, int y_ld, LenMap len) {
+    extern __shared__ __attribute__((aligned(16))) float lstm_smem[];
+    float* hs = lstm_smem;                                     // [4][LSTMP_HP]
+    float* gates = hs + 4 * LSTMP_HP;                          // [1024] gate pre-activations, index = row of W_hh
+    float4* wl = reinterpret_cast<float4*>(gates + 1024);      // [LSTMS_LDS][1024]
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    const int L = len_of(len, b);
+    const int kq = tid & 3, rp = tid >> 2;
+    // rows 2 rp, 2 rp + 1 of half p (the two-CU form's mapping: gate r >> 7, unit 128 p + (r & 127)); row B = row A + 1
+    const int rr = 2 * rp;
+    const int rowA0 = (rr >> 7) * 256 + (rr & 127), rowA1 = rowA0 + 128;
+    const float4* W4 = reinterpret_cast<const float4*>(whhT + (long)dir * 256 * 1024) + (long)kq * 16 * 1024;
+    float4 wreg[LSTMS_REG];
+#pragma unroll
+    for (int i = 0; i < LSTMS_REG; ++i) wreg[i] = W4[(long)(i >> 1) * 1024 + rowA0 + (i & 1)];
+#pragma unroll
+    for (int i = 0; i < LSTMS_LDS; ++i) wl[i * 1024 + tid] = W4[(long)((LSTMS_REG + i) >> 1) * 1024 + rowA0 + (i & 1)];
+    if (tid < 4 * LSTMP_HP) hs[tid] = 0.f;
+    float c = 0.f;
+    // lanes kq = 0 / 1 of a quad finish row A / B of each half: they carry its input projection
+    const int myrow0 = rowA0 + (kq & 1), myrow1 = rowA1 + (kq & 1);
+    const float* gxp = gx + b * gx_bs + dir * 1024;
+    float gxv0 = (kq < 2 && L > 0) ? gxp[(long)(dir ? L - 1 : 0) * gx_ld + myrow0] : 0.f;
+    float gxv1 = (kq < 2 && L > 0) ? gxp[(long)(dir ? L - 1 : 0) * gx_ld + myrow1] : 0.f;
+    auto hslot = [](int k) { return (k >> 6) * LSTMP_HP + (k & 63); };
+    auto fma8 = [](const float4& wa, const float4& wb, const float4& hv, float& accA, float& accB) __attribute__((always_inline)) {
+        accA = fmaf(wa.x, hv.x, accA);
+        accB = fmaf(wb.x, hv.x, accB);
+        accA = fmaf(wa.y, hv.y, accA);
+        accB = fmaf(wb.y, hv.y, accB);
+        accA = fmaf(wa.z, hv.z, accA);
+        accB = fmaf(wb.z, hv.z, accB);
+        accA = fmaf(wa.w, hv.w, accA);
+        accB = fmaf(wb.w, hv.w, accB);
+    };
+    __syncthreads();
+    for (int step = 0; step < L; ++step) {
+        const int t = dir ? (L - 1 - step) : step;
+        const float4* h4 = reinterpret_cast<const float4*>(hs + kq * LSTMP_HP);
+        // half 1 first in program order (all of it streamed: its loads are in flight while half 0's resident part is summed)
+        float a1 = 0.f, b1 = 0.f;
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            const float4 wa = W4[(long)j * 1024 + rowA1], wb = W4[(long)j * 1024 + rowA1 + 1];
+            fma8(wa, wb, h4[j], a1, b1);
+        }
+        float a0 = 0.f, b0 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LSTMS_REG / 2; ++j) fma8(wreg[2 * j], wreg[2 * j + 1], h4[j], a0, b0);
+#pragma unroll
+        for (int j = 0; j < LSTMS_LDS / 2; ++j) fma8(wl[(2 * j) * 1024 + tid], wl[(2 * j + 1) * 1024 + tid], h4[LSTMS_REG / 2 + j], a0, b0);
+#pragma unroll
+        for (int j = (LSTMS_REG + LSTMS_LDS) / 2; j < 16; ++j) {
+            const float4 wa = W4[(long)j * 1024 + rowA0], wb = W4[(long)j * 1024 + rowA0 + 1];
+            fma8(wa, wb, h4[j], a0, b0);
+        }
+        a0 += __shfl_xor(a0, 1);
+        b0 += __shfl_xor(b0, 1);
+        a0 += __shfl_xor(a0, 2);
+        b0 += __shfl_xor(b0, 2);
+        a1 += __shfl_xor(a1, 1);
+        b1 += __shfl_xor(b1, 1);
+        a1 += __shfl_xor(a1, 2);
+        b1 += __shfl_xor(b1, 2);
+        if (kq < 2) {
+            gates[myrow0] = gxv0 + ((kq & 1) ? b0 : a0);
+            gates[myrow1] = gxv1 + ((kq & 1) ? b1 : a1);
+            if (step + 1 < L) {
+                gxv0 = gxp[(long)(dir ? t - 1 : t + 1) * gx_ld + myrow0];
+                gxv1 = gxp[(long)(dir ? t - 1 : t + 1) * gx_ld + myrow1];
+            }
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const float hn = lstm_cell(gates[tid], gates[256 + tid], gates[512 + tid], gates[768 + tid], c);
+            hs[hslot(tid)] = hn;
+            y[b * y_bs + (long)(dir * 256 + tid) * y_ld + t] = hn;
+        }
+        __syncthreads();
+    }
+}
+
 // test hook (kx_test_lstm_fault): n > 0 = from the n-th launch of the two-CU kernel on, every launch loses the second half
 // of each pair and polls with a short limit, so that the bounded wait's error path can be exercised (n = 6: the
 // frame-axis LSTM of a forward, which runs after the forward's mid-way error check)
 static std::atomic<int> lstm_test_fault{0};
 void lstm_set_test_fault(int nth) { lstm_test_fault.store(nth > 0 ? nth : 0); }
 
-// 0 = by batch size, 2 / 4 = that many workgroups per (utterance, direction) (KX_LSTM_PARTS; kx_test_lstm_parts)
+// 0 = by batch size, 2 / 4 = that many workgroups per (utterance, direction), 1 = the streaming fall-back (KX_LSTM_PARTS; kx_test_lstm_parts)
 static std::atomic<int> lstm_parts_force{getenv("KX_LSTM_PARTS") ? atoi(getenv("KX_LSTM_PARTS")) : 0};
-void lstm_set_parts(int n) { lstm_parts_force.store(n == 2 || n == 4 ? n : 0); }
+void lstm_set_parts(int n) { lstm_parts_force.store(n == 1 || n == 2 || n == 4 ? n : 0); }  // (1 = the streaming fall-back)
 
 static bool lstm_use_pair() {
     static const int v = getenv("KX_LSTM_PAIR") ? atoi(getenv("KX_LSTM_PAIR")) : 1;
@@ -788,7 +889,7 @@ size_t lstm_exchange_bytes(int B) { return (size_t)B * 2 * 2 * 2 * 128 * sizeof(
 void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, float* y, long y_bs, int y_ld,
                  LenMap len, int B, unsigned long long* xchg, unsigned* err_word, hipStream_t s, unsigned* epoch_state) {
     static_assert(LSTM_LDS_K % 4 == 0 && LSTM_REG_K % 4 == 0, "whole float4 groups of h");
-    if (lstm_use_pair() && xchg && err_word) {
+    if (lstm_use_pair() && xchg && err_word && lstm_parts_force.load() != 1) {
         // The tag's epoch is 16 bits wide and counted PER exchange buffer (epoch_state; the test hook's one-shot buffer has
         // none): when it wraps the buffer is cleared in stream order, so a granule of 65535 launches ago can never carry
         // the tag of a live step.  (0 is what a cleared buffer holds and is never used as an epoch.)
@@ -815,7 +916,7 @@ void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, floa
         // KX_LSTM_PARTS = 2 / 4 forces a form.
         const int parts = lstm_parts_force.load();
         const bool four = parts ? parts == 4 : 8 * B <= conv16_cu_count();
-        const int spin = fault ? (1 << 10) : (1 << 22);
+        const int spin = fault ? (1 << 10) : (1 << 19);
         if (four) {
             using P4 = LstmParts<4>;
             const size_t lds = sizeof(float) * (4 * LSTMP_HP + P4::ROWS + 4 + (size_t)P4::LDSP * P4::THREADS * 4);
@@ -829,6 +930,14 @@ void launch_lstm(const float* gx, long gx_bs, int gx_ld, const float* whhT, floa
             hipLaunchKernelGGL(lstm_pair_kernel<2>, dim3(((n_pairs + 7) / 8) * 16), dim3(P2::THREADS), lds, s, gx, gx_bs, gx_ld, whhT, y,
                                y_bs, y_ld, len, xchg, epoch, err_word, n_pairs, spin, fault);
         }
+        KX_HIP(hipGetLastError());
+        return;
+    }
+    if (lstm_use_pair()) {  // the fall-back of a model whose hand-off timed out (xchg = null): same bits as the resident forms
+        const size_t lds = sizeof(float) * (4 * LSTMP_HP + 1024 + (size_t)LSTMS_LDS * 1024 * 4);
+        static DynLdsLimit stream_limit;
+        stream_limit.ensure(reinterpret_cast<const void*>(lstm_stream_kernel), lds);
+        hipLaunchKernelGGL(lstm_stream_kernel, dim3(B, 2), dim3(1024), lds, s, gx, gx_bs, gx_ld, whhT, y, y_bs, y_ld, len);
         KX_HIP(hipGetLastError());
         return;
     }

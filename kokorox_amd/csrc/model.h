@@ -93,6 +93,12 @@ struct ConvOpts {
 std::vector<unsigned char> read_weight_file(const char* path);
 std::vector<unsigned char> import_onnx_bytes(const unsigned char* data, size_t n);  // ImportError -> Error(KX_ERR_IO)
 
+// (KX_ERR_DEVICE class) a part of a resident-weights LSTM recurrence timed out waiting for its partner: the call is invalid,
+// the model has switched to the streaming recurrence; host entry points re-run the call once
+struct LstmTimeout : Error {
+    explicit LstmTimeout(const std::string& m) : Error(3, m) {}
+};
+
 class Model {
   public:
     Model(int device);
@@ -124,10 +130,19 @@ class Model {
     void infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* lens, int B, const float* speeds,
                        int n_speed, uint64_t seed, uint32_t flags, const HostCall& hc, void** out, int64_t* out_bytes,
                        int64_t* out_samples);
+    // [0] recurrence in use: 0 = resident weights (two / four workgroups), 1 = the streaming fall-back; [1] hand-off time-outs so
+    // far; [2] clean forwards left until the resident forms return (0 when they are in use); [3] calls re-run transparently
+    void status(int64_t out[4]) const;
+    // kx_infer_device + kx_sync: the forward finished cleanly (counts towards the resident forms' return)
+    void note_clean_forward();
+    void note_rerun() { n_rerun_ += 1; }
+    static constexpr int LSTM_REARM_AFTER = 64;
     void set_voice_table(const float* table, int n_voices);
     int n_voices() const { return n_voices_.load(std::memory_order_acquire); }  // (read by the dispatcher without the mutex)
+    int n_vocab() const { return n_vocab_; }                                    // (fixed once the model is built)
     void sync();
     void order_after_null_stream();
+    void order_null_stream_after();
     void set_pinned(const int32_t* pattern, int n);
     // one forward of B utterances x n_tokens with every duration pinned to frames_per_token, output discarded: sizes the arenas,
     // the pooled page-locked buffer and the flat tile tables for that shape before the first real request
@@ -235,7 +250,11 @@ class Model {
     size_t xchg_cap_ = 0;
     unsigned xchg_epoch_[2] = {0, 0};  // launches on each exchange buffer since it was last cleared (16-bit tag epoch)
     bool p1_region_ = false;           // inside the part of the forward whose direct-A convs may run reduced precision
-    bool lstm_pair_ok_ = true;         // false once a hand-off timed out: the one-CU kernel from then on
+    bool lstm_pair_ok_ = true;         // false after a hand-off time-out: the streaming recurrence until lstm_rearm_in_ forwards were clean
+    int lstm_rearm_in_ = 0;
+    int64_t n_lstm_timeouts_ = 0, n_rerun_ = 0;
+    void infer_host_once(const int64_t* ids, int64_t t_stride, const int32_t* lens, int B, const float* speeds, int n_speed,
+                         uint64_t seed, uint32_t flags, const HostCall& hc, void** out, int64_t* out_bytes, int64_t* out_samples);
     std::vector<long> h_off_;          // host staging that asynchronous copies read / write: outlives the calling frame
     unsigned h_bad_id_ = 0;
     unsigned* d_dev_err_ = nullptr;
@@ -244,6 +263,7 @@ class Model {
     size_t h_stage_cap_ = 0;
     int* stage_ints(size_t n);
     hipEvent_t ev_null_ = nullptr;   // orders kx_infer_device's inputs after the caller's null-stream work
+    hipEvent_t ev_done_ = nullptr;   // ... and the caller's later null-stream work after the forward (order_null_stream_after)
     hipStream_t main_stream_ = nullptr;
     void check_dev_err();
     unsigned* d_bad_id_ = nullptr;  // sticky word: first out-of-table token id seen by the embedding kernels

@@ -23,6 +23,9 @@ Model::Model(int dev) : device(dev) {
     if (const char* e = getenv("KOKOROX_CONV"))
         conv_mode = (strcmp(e, "f32") == 0) ? CONV_F32 : (strcmp(e, "f16") == 0 ? CONV_F16 : CONV_F16X3);
     if (const char* e = getenv("KOKOROX_STFT")) stft_variant = (strcmp(e, "torch") == 0) ? STFT_TORCH : STFT_ONNX;
+    // (per-device state of the library -- the per-device turn of the forwards, dynamic-LDS attribute limits, CU counts -- is
+    // kept in tables of KX_MAX_DEVICES entries: an id beyond them is refused here, never aliased onto another device's entry)
+    if (dev < 0 || dev >= KX_MAX_DEVICES) throw Error(1, "device id outside 0.." + std::to_string(KX_MAX_DEVICES - 1));
     KX_HIP(hipSetDevice(device));
     // Non-blocking: the model's streams never synchronise with the legacy null stream, so nothing one model does can stall
     // another model on the same GPU (two models per GPU in the server, kx_create_replicas with repeated ids).  Everything
@@ -60,6 +63,7 @@ Model::~Model() {
     if (h_words_) (void)hipHostFree(h_words_);
     if (h_stage_) (void)hipHostFree(h_stage_);
     if (ev_null_) (void)hipEventDestroy(ev_null_);
+    if (ev_done_) (void)hipEventDestroy(ev_done_);
     for (auto* p : d_xchg_)
         if (p) (void)hipFree(p);
     for (Arena* a : {&arenaT_, &arenaF_, &arenaIO_})
@@ -149,22 +153,36 @@ std::vector<unsigned char> read_weight_file(const char* path) {
         if (total != host.size()) throw Error(2, "weight blob: file size does not match header");
         return host;
     }
-    const std::string cache = std::string(path) + ".kxw";
-    struct stat so, sc;
-    if (stat(path, &so) == 0 && stat(cache.c_str(), &sc) == 0 && sc.st_mtime >= so.st_mtime) {
+    // The converted image may be cached beside the source -- ONLY when KOKOROX_KXW_CACHE=1 says so (a file the library never wrote
+    // is never trusted), and only while the cache's stamp names exactly this source: its size, its modification time to the
+    // nanosecond and the importer's version (cp -p / mv / a re-pointed Hugging Face blob symlink keep an older mtime: a "not
+    // older than the source" test would load the former variant's weights).
+    const std::string cache = std::string(path) + ".kxw", stamp_path = cache + ".src";
+    const char* ce = getenv("KOKOROX_KXW_CACHE");
+    const bool use_cache = ce && strcmp(ce, "1") == 0;
+    struct stat so;
+    std::string stamp;
+    if (use_cache && stat(path, &so) == 0) {
+        stamp = "kxw-cache 1 importer " + std::to_string(KX_IMPORTER_VERSION) + " size " + std::to_string((long long)so.st_size) + " mtime " +
+                std::to_string((long long)so.st_mtim.tv_sec) + "." + std::to_string((long)so.st_mtim.tv_nsec) + "\n";
         try {
-            std::vector<unsigned char> c = read_all(cache.c_str(), "weight cache");
-            if (is_kxw_magic(c.data(), c.size()) && check_header(c.data(), c.size()) == c.size()) return c;
-        } catch (const Error&) {  // an unreadable cache is not an error: convert again
+            const std::vector<unsigned char> st = read_all(stamp_path.c_str(), "weight cache stamp");
+            if (std::string(st.begin(), st.end()) == stamp) {
+                std::vector<unsigned char> c = read_all(cache.c_str(), "weight cache");
+                if (is_kxw_magic(c.data(), c.size()) && check_header(c.data(), c.size()) == c.size()) return c;
+            }
+        } catch (const Error&) {  // no cache, or an unreadable one, is not an error: convert
         }
     }
     std::vector<unsigned char> blob = import_onnx_bytes(host.data(), host.size());
-    if (const char* e = getenv("KOKOROX_KXW_CACHE")) {
-        if (strcmp(e, "1") == 0) {
-            const std::string tmp = cache + ".tmp." + std::to_string((long)getpid());
-            if (FILE* f = fopen(tmp.c_str(), "wb")) {
-                const bool ok = fwrite(blob.data(), 1, blob.size(), f) == blob.size();
-                if (fclose(f) != 0 || !ok || rename(tmp.c_str(), cache.c_str()) != 0) (void)remove(tmp.c_str());
+    if (use_cache && !stamp.empty()) {
+        const std::string tmp = cache + ".tmp." + std::to_string((long)getpid());
+        if (FILE* f = fopen(tmp.c_str(), "wb")) {
+            const bool ok = fwrite(blob.data(), 1, blob.size(), f) == blob.size();
+            if (fclose(f) != 0 || !ok || rename(tmp.c_str(), cache.c_str()) != 0) (void)remove(tmp.c_str());
+            else if (FILE* g = fopen((stamp_path + ".tmp").c_str(), "wb")) {  // (the stamp last: a cache without it is ignored)
+                const bool ok2 = fwrite(stamp.data(), 1, stamp.size(), g) == stamp.size();
+                if (fclose(g) != 0 || !ok2 || rename((stamp_path + ".tmp").c_str(), stamp_path.c_str()) != 0) (void)remove((stamp_path + ".tmp").c_str());
             }
         }
     }
@@ -888,10 +906,27 @@ void Model::check_dev_err() {
     if (!e) return;
     KX_HIP(hipMemsetAsync(d_dev_err_, 0, sizeof(unsigned), main_stream_));
     KX_HIP(hipStreamSynchronize(main_stream_));
+    // A part of a resident-weights recurrence never saw its partner (starved behind other work on the GPU): what this call
+    // computed is garbage.  The model switches to the streaming recurrence -- same bits, no partner to wait for -- and goes back
+    // to the resident forms after LSTM_REARM_AFTER clean forwards; the host entry points re-run the call once (infer_host_ex).
     lstm_pair_ok_ = false;
-    throw Error(3, "device error word " + std::to_string(e) +
-                       ": a half of the two-CU LSTM recurrence never saw its partner; this call failed, the model uses the "
-                       "one-CU kernel from now on (KX_LSTM_PAIR=0 selects it from the start)");
+    lstm_rearm_in_ = LSTM_REARM_AFTER;
+    n_lstm_timeouts_ += 1;
+    throw LstmTimeout("device error word " + std::to_string(e) +
+                      ": a part of the resident-weights LSTM recurrence never saw its partner; this call's result is invalid; the "
+                      "model runs the streaming recurrence (same bits) for the next " + std::to_string(LSTM_REARM_AFTER) + " forwards");
+}
+
+void Model::status(int64_t out[4]) const {
+    out[0] = lstm_pair_ok_ ? 0 : 1;
+    out[1] = n_lstm_timeouts_;
+    out[2] = lstm_pair_ok_ ? 0 : lstm_rearm_in_;
+    out[3] = n_rerun_;
+}
+
+// a forward has finished cleanly: count down to the resident-weights recurrence's return
+void Model::note_clean_forward() {
+    if (!lstm_pair_ok_ && lstm_rearm_in_ > 0 && --lstm_rearm_in_ == 0) lstm_pair_ok_ = true;
 }
 
 void Model::set_pinned(const int32_t* pattern, int n) {
@@ -1053,7 +1088,14 @@ struct DeviceGate {
 };
 DeviceGate& device_gate(int dev) {
     static DeviceGate g[KX_MAX_DEVICES];
-    return g[(dev >= 0 && dev < KX_MAX_DEVICES) ? dev : 0];
+    if (dev < 0 || dev >= KX_MAX_DEVICES) throw Error(1, "device id outside 0.." + std::to_string(KX_MAX_DEVICES - 1));  // (the Model constructor refuses such ids)
+    return g[dev];
+}
+// KX_DEVICE_TURN=0: the models of one device run their forwards side by side (tests; see kx_model_status for what then happens
+// to a starved recurrence)
+bool device_turn_on() {
+    static const bool on = !(getenv("KX_DEVICE_TURN") && atoi(getenv("KX_DEVICE_TURN")) == 0);
+    return on;
 }
 }  // namespace
 
@@ -1061,10 +1103,14 @@ struct Model::DeviceTurn {
     Model& m;
     DeviceGate& g;
     std::unique_lock<std::mutex> lk;
-    explicit DeviceTurn(Model& mm) : m(mm), g(device_gate(mm.device)), lk(g.mu) {
+    const bool on;
+    explicit DeviceTurn(Model& mm) : m(mm), g(device_gate(mm.device)), lk(g.mu, std::defer_lock), on(device_turn_on()) {
+        if (!on) return;
+        lk.lock();
         if (g.last && g.owner != &m) KX_HIP(hipStreamWaitEvent(m.main_stream_, g.last, 0));
     }
     ~DeviceTurn() {  // (also on a failed forward: whatever it queued is what the next model has to wait for)
+        if (!on) return;
         if (!g.last && hipEventCreateWithFlags(&g.last, hipEventDisableTiming) != hipSuccess) g.last = nullptr;
         if (g.last && hipEventRecord(g.last, m.main_stream_) == hipSuccess) g.owner = &m;
         else g.owner = nullptr;
@@ -1520,6 +1566,17 @@ void Model::order_after_null_stream() {
     KX_HIP(hipStreamWaitEvent(stream_, ev_null_, 0));
 }
 
+// ... and on the way out: the model's streams are non-blocking, so work the caller queues on the legacy null stream AFTER
+// kx_infer_device returns (torch's default stream reading d_audio, or overwriting d_ids / d_styles for the next request) would
+// race with the back half that is still queued.  The null stream waits, on the GPU, for the end of this forward: a caller on
+// the null stream is ordered as it was when the model's stream was a blocking one; no host stall.  (Callers on other streams
+// must use kx_sync: the header says so.)
+void Model::order_null_stream_after() {
+    if (!ev_done_) KX_HIP(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
+    KX_HIP(hipEventRecord(ev_done_, main_stream_));
+    KX_HIP(hipStreamWaitEvent(nullptr, ev_done_, 0));
+}
+
 void Model::set_voice_table(const float* table, int n_voices) {
     KX_REQUIRE(table && n_voices >= 1 && n_voices <= 4096, "voice table: 1..4096 voices of [511][256] floats");
     KX_HIP(hipSetDevice(device));
@@ -1554,9 +1611,23 @@ void Model::infer_host(const int64_t* ids, int64_t t_stride, const int32_t* lens
     *out = static_cast<float*>(p);
 }
 
+// A hand-off time-out of the resident-weights recurrence invalidates the call it happened in, not the request: the host entry
+// points run the call once more, now on the streaming recurrence (same bits), and the caller sees a result, not an error.
 void Model::infer_host_ex(const int64_t* ids, int64_t t_stride, const int32_t* lens, int B, const float* speeds,
                           int n_speed, uint64_t seed, uint32_t flags, const HostCall& hc, void** out,
                           int64_t* out_bytes, int64_t* out_samples) {
+    try {
+        infer_host_once(ids, t_stride, lens, B, speeds, n_speed, seed, flags, hc, out, out_bytes, out_samples);
+    } catch (const LstmTimeout&) {
+        n_rerun_ += 1;
+        infer_host_once(ids, t_stride, lens, B, speeds, n_speed, seed, flags, hc, out, out_bytes, out_samples);
+    }
+    note_clean_forward();
+}
+
+void Model::infer_host_once(const int64_t* ids, int64_t t_stride, const int32_t* lens, int B, const float* speeds,
+                            int n_speed, uint64_t seed, uint32_t flags, const HostCall& hc, void** out,
+                            int64_t* out_bytes, int64_t* out_samples) {
     KX_REQUIRE(out && out_bytes && out_samples, "infer: null output argument");
     *out = nullptr;
     KX_REQUIRE(B >= 1, "infer: empty batch");

@@ -19,6 +19,9 @@
 
 namespace kx {
 
+// bumped whenever the placement rules change what the importer writes for the same .onnx (it stamps the opt-in cache: model.hip)
+constexpr int KX_IMPORTER_VERSION = 1;
+
 struct ImportError : std::runtime_error {
     explicit ImportError(const std::string& m) : std::runtime_error(m) {}
 };

@@ -74,6 +74,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_warmup": (i32, [vp, i32, i32, i32]),
         "kx_arena_bytes": (i32, [vp, C.POINTER(i64)]),
         "kx_call_times": (i32, [vp, C.POINTER(C.c_double)]),
+        "kx_model_status": (i32, [vp, C.POINTER(i64)]),
+        "kx_dispatcher_health": (i32, [vp, vp, i32, C.POINTER(i64), C.POINTER(i64)]),
         "kx_create_from_device_blob": (vp, [vp, sz, i32, cp, sz]),
         "kx_destroy": (None, [vp]),
         "kx_last_error": (cp, [vp]),
@@ -166,7 +168,7 @@ TEST_ABI_SYMBOLS = ["kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test
 ABI_SYMBOLS = [
     "kx_version", "kx_init", "kx_create", "kx_import_onnx", "kx_create_from_device_blob", "kx_create_replicas", "kx_destroy",
     "kx_last_error", "kx_last_error_copy", "kx_infer",
-    "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_warmup", "kx_arena_bytes", "kx_call_times", "kx_set_utterance_base", "kx_set_lanes",
+    "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_warmup", "kx_arena_bytes", "kx_call_times", "kx_model_status", "kx_dispatcher_health", "kx_set_utterance_base", "kx_set_lanes",
     "kx_set_conv_mode", "kx_get_conv_mode", "kx_set_stft_variant", "kx_get_stft_variant",
     "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_profile_aux", "kx_diag_enable", "kx_diag_count", "kx_diag_get", "kx_set_act_prescale", "kx_set_voice_table", "kx_infer_voices",
     "kx_infer_packed", "kx_free_packed", "kx_dispatcher_create", "kx_dispatcher_submit", "kx_dispatcher_submit_ex", "kx_dispatcher_model_batches",
@@ -362,6 +364,12 @@ class HipKoko:
         self._check(self._lib.kx_arena_bytes(self._h, out))
         return list(out)
 
+    def status(self):
+        """[recurrence in use (0 resident / 1 streaming), hand-off time-outs, clean forwards until the resident forms return, re-run calls]."""
+        out = (C.c_int64 * 4)()
+        self._check(self._lib.kx_model_status(self._h, out))
+        return list(out)
+
     def call_times(self):
         """Host milestones of the last call in ms from its entry: [front queued, front done (the host wait), back planned, back queued]."""
         out = (C.c_double * 4)()
@@ -525,8 +533,12 @@ class Dispatcher:
         self._lib.kx_dispatcher_model_batches(self._d, per, len(self._models))
         rp, rt = C.c_int64(0), C.c_int64(0)
         self._lib.kx_dispatcher_failures(self._d, C.byref(rp), C.byref(rt))
+        hl = (C.c_int32 * len(self._models))()
+        mf, rq = C.c_int64(0), C.c_int64(0)
+        self._lib.kx_dispatcher_health(self._d, hl, len(self._models), C.byref(mf), C.byref(rq))
         return {"requests": a.value, "batches": b.value, "max_batch": c.value, "batches_per_model": list(per),
-                "replayed_requests": rp.value, "retried_batches": rt.value}
+                "replayed_requests": rp.value, "retried_batches": rt.value, "healthy": [int(v) for v in hl],
+                "failed_models": mf.value, "requeued_requests": rq.value}
 
     def close(self):
         if getattr(self, "_d", None):

@@ -28,6 +28,8 @@ struct StubModel {
     int fail_every = 0;             // every n-th batch fails once with DEVICE (the retry then succeeds)
     bool dead = false;              // every batch fails with DEVICE
     int sleep_us = 300;
+    int distribute_us = 150;
+    int vocab = 178;
 };
 struct StubHandle {
     std::unique_ptr<StubModel> m;
@@ -53,8 +55,11 @@ struct StubBackend {
     using Handle = StubHandle;
     struct Out {
         std::vector<std::vector<unsigned char>> parts;  // the "packed batch": one entry per request
+        int distribute_us = 0;
     };
     static int n_voices(StubHandle* h) { return h->m->voices.load(); }
+    static int n_vocab(StubHandle* h) { return h->m->vocab; }
+    static void free_out(void* p) { free(p); }
     static int forward(StubHandle* h, std::vector<Request*>& batch, Out& o) {
         StubModel& M = *h->m;
         std::unique_lock<std::mutex> lk(M.mu, std::try_to_lock);
@@ -66,7 +71,7 @@ struct StubBackend {
             return KX_ERR_STATE;
         }
         const long nth = ++M.batches;
-        std::this_thread::sleep_for(std::chrono::microseconds(M.sleep_us));
+        if (M.sleep_us) std::this_thread::sleep_for(std::chrono::microseconds(M.sleep_us));
         int rc = KX_OK;
         std::string err;
         if (M.dead || (M.fail_every && nth % M.fail_every == 0)) {
@@ -80,6 +85,7 @@ struct StubBackend {
                 }
         }
         o.parts.clear();
+        o.distribute_us = M.distribute_us;
         for (Request* r : batch) {
             r->rc = rc;
             r->err = err;
@@ -91,7 +97,7 @@ struct StubBackend {
         return rc;
     }
     static void distribute(std::vector<Request*>& batch, Out& o) {
-        std::this_thread::sleep_for(std::chrono::microseconds(150));  // host work beside the next forward
+        if (o.distribute_us) std::this_thread::sleep_for(std::chrono::microseconds(o.distribute_us));  // host work beside the next forward
         for (size_t i = 0; i < batch.size(); ++i) {
             Request* r = batch[i];
             const std::vector<unsigned char>& e = o.parts[i];
@@ -212,12 +218,13 @@ void scenario_mixed_load() {
 }
 
 void scenario_dead_model() {
-    // a model whose every batch fails: each batch is tried exactly twice (never once per request), its requests report DEVICE
+    // the only model's every batch fails: the first batch is tried exactly twice (never once per request), then the model is
+    // marked failed, what is queued reports DEVICE at once and later submits are refused without ever reaching a batch
     std::vector<StubHandle> hs = make_models(1);
     hs[0].m->dead = true;
     StubHandle* ptr[1] = {&hs[0]};
     ClientTotals tot;
-    long batches, core_batches;
+    long batches, core_batches, model_failures;
     {
         Core core(ptr, 1, 32, 2000);
         std::vector<std::thread> th;
@@ -229,10 +236,73 @@ void scenario_dead_model() {
         for (auto& t : th) t.join();
         std::lock_guard<std::mutex> lk(core.mu);
         core_batches = (long)core.n_batches;
+        model_failures = (long)core.n_model_failures;
+        CHECK(core.failed[0] == 1 && core.healthy_models() == 0, "the model is not marked failed");
     }
     batches = hs[0].m->batches.load();
     CHECK(tot.device == 128 && tot.ok == 0 && tot.wrong == 0, "device %ld ok %ld wrong %ld", tot.device.load(), tot.ok.load(), tot.wrong.load());
-    CHECK(batches == 2 * core_batches, "%ld forwards for %ld batches (want exactly one retry each)", batches, core_batches);
+    CHECK(core_batches == 1 && batches == 2 && model_failures == 1, "%ld forwards for %ld batches, %ld model failures (want one batch, tried twice)", batches,
+          core_batches, model_failures);
+}
+
+void scenario_one_faulted_model_of_three() {
+    // Round 5 (the advisor's case): model 0 has a sticky fault -- every forward fails with DEVICE.  It must be fenced off after its
+    // first batch (tried twice), that batch must be served by the healthy models, and NO request may fail; before, the dead
+    // model counted as free at once after every failure and kept taking its share of the queue, failing each batch twice.
+    std::vector<StubHandle> hs = make_models(3);
+    hs[0].m->dead = true;
+    StubHandle* ptr[3] = {&hs[0], &hs[1], &hs[2]};
+    ClientTotals tot;
+    {
+        Core core(ptr, 3, 8, 300);
+        std::vector<std::thread> th;
+        for (int c = 0; c < 48; ++c)
+            th.emplace_back([&, c] {
+                unsigned rng = 4242u + (unsigned)c * 13u;
+                for (int i = 0; i < 20; ++i) one_request(core, rng, false, tot);
+            });
+        for (auto& t : th) t.join();
+        std::lock_guard<std::mutex> lk(core.mu);
+        CHECK(core.failed[0] == 1 && core.failed[1] == 0 && core.failed[2] == 0, "health %d %d %d", core.failed[0], core.failed[1], core.failed[2]);
+        CHECK(core.n_model_failures == 1 && core.n_requeued > 0 && core.n_retried == 1, "failures %ld requeued %ld retried %ld", (long)core.n_model_failures,
+              (long)core.n_requeued, (long)core.n_retried);
+        CHECK(core.per_model_batches[0] == 1, "the faulted model took %ld batches (want exactly one)", (long)core.per_model_batches[0]);
+    }
+    CHECK(hs[0].m->batches.load() == 2, "%ld forwards on the faulted model (want its one batch, tried twice)", hs[0].m->batches.load());
+    CHECK(tot.ok == 48 * 20 && tot.device == 0 && tot.wrong == 0 && tot.state == 0, "ok %ld device %ld wrong %ld", tot.ok.load(), tot.device.load(),
+          tot.wrong.load());
+}
+
+// Queue throughput with forwards that cost nothing: what the host side can dispatch per second in front of 8 models (the 8-GPU
+// server of BASELINE configs[4] needs ~8 x 555 requests/s at the measured per-GPU rate).  Not a sanitizer scenario: built -O2.
+int throughput() {
+    std::vector<StubHandle> hs = make_models(8);
+    StubHandle* ptr[8];
+    for (int i = 0; i < 8; ++i) {
+        hs[(size_t)i].m->sleep_us = 0;
+        hs[(size_t)i].m->distribute_us = 0;
+        ptr[i] = &hs[(size_t)i];
+    }
+    ClientTotals tot;
+    const int clients = 64, per_client = 2000;
+    const auto t0 = std::chrono::steady_clock::now();
+    long batches;
+    {
+        Core core(ptr, 8, 64, 200);
+        std::vector<std::thread> th;
+        for (int c = 0; c < clients; ++c)
+            th.emplace_back([&, c] {
+                unsigned rng = 1u + (unsigned)c;
+                for (int i = 0; i < per_client; ++i) one_request(core, rng, false, tot);
+            });
+        for (auto& t : th) t.join();
+        std::lock_guard<std::mutex> lk(core.mu);
+        batches = (long)core.n_batches;
+    }
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("throughput: %.0f requests/s (%d clients x %d requests over 8 zero-cost models, %ld batches, %.3f s, %ld wrong)\n",
+           clients * per_client / sec, clients, per_client, batches, sec, tot.wrong.load() + (long)(clients * per_client) - tot.ok.load());
+    return (tot.ok == clients * per_client && tot.wrong == 0) ? 0 : 1;
 }
 
 void scenario_refused_at_submit() {
@@ -257,7 +327,11 @@ void scenario_refused_at_submit() {
     CHECK(core.submit_ex(ids.data(), 4, style.data(), nullptr, nullptr, 0, 0.f, 0, 0, &out, &nb, &ns, err, sizeof err) == KX_ERR_INVALID, "speed 0");
     CHECK(core.submit_ex(ids.data(), 4, style.data(), nullptr, nullptr, 0, 1.f, 0, 3, &out, &nb, &ns, err, sizeof err) == KX_ERR_INVALID, "format 3");
     std::vector<int64_t> bad_ids = {0, 178, 0};
-    CHECK(core.submit_ex(bad_ids.data(), 3, style.data(), nullptr, nullptr, 0, 1.f, 0, 0, &out, &nb, &ns, err, sizeof err) == KX_ERR_INVALID, "token id");
+    CHECK(core.submit_ex(bad_ids.data(), 3, style.data(), nullptr, nullptr, 0, 1.f, 0, 0, &out, &nb, &ns, err, sizeof err) == KX_ERR_INVALID && strstr(err, "0..177"), "token id: %s", err);
+    hs[0].m->vocab = 100;  // the bound comes from the models' embedding tables (the smallest decides), not from a constant
+    std::vector<int64_t> ids_100 = {0, 100, 0};
+    CHECK(core.submit_ex(ids_100.data(), 3, style.data(), nullptr, nullptr, 0, 1.f, 0, 0, &out, &nb, &ns, err, sizeof err) == KX_ERR_INVALID && strstr(err, "0..99"), "token id vs a 100-row table: %s", err);
+    hs[0].m->vocab = 178;
     int32_t ok_v[1] = {9};
     CHECK(core.submit_ex(ids.data(), 4, nullptr, ok_v, nullptr, 1, 1.f, 0, 2, &out, &nb, &ns, err, sizeof err) == KX_OK && nb == 4 * 10 * 2, "valid single voice: %s", err);
     free(out);
@@ -348,11 +422,13 @@ void scenario_guard_and_last_error() {
 
 }  // namespace
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1 && strcmp(argv[1], "throughput") == 0) return throughput();
     scenario_guard_and_last_error();
     scenario_refused_at_submit();
     scenario_mixed_load();
     scenario_dead_model();
+    scenario_one_faulted_model_of_three();
     scenario_destroy_while_queued();
     if (failures) {
         fprintf(stderr, "%d check(s) failed\n", failures);

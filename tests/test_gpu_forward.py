@@ -136,37 +136,74 @@ def test_lanes_do_not_change_a_bit(hip_model):
         hip_model.set_lanes(0)
 
 
-def test_lstm_handoff_timeout_fails_the_call_it_belongs_to(blob_path):
-    """A half of the two-CU LSTM whose partner never shows up raises the sticky device error word and leaves.  The call
-    whose audio that garbles must fail itself (KX_ERR_DEVICE), also when it happens in the frame-axis LSTM after the
-    forward's mid-way check; the model then uses the one-CU kernel and the next call gives the undisturbed result."""
+def test_lstm_handoff_timeout_is_survived_without_changing_a_bit(blob_path):
+    """A part of a resident-weights LSTM recurrence whose partner never shows up raises the sticky device error word and leaves:
+    what that call computed is garbage.  Round 5: the model switches to the streaming recurrence -- which gives the SAME BITS --
+    and the host entry points run the call once more, so the caller gets the undisturbed result, not an error; kx_model_status
+    reports the time-out, the fall-back and the re-run, and the resident forms return after 64 clean forwards.  On the
+    device-pointer path a time-out of a token-axis recurrence is re-run the same way (seen at the forward's one host wait); one of
+    the frame-axis recurrence shows only at kx_sync, which must fail with KX_ERR_DEVICE (never hand out garbage)."""
     from kokorox_amd import hip_koko as hk
+    import torch
     ids, styles = _inputs([12], seed0=310)
     m = hk.HipKoko.new(blob_path)
     names = ("text_enc.out", "dur.lstm", "pred.F0", "pred.N", "dec.decode.3")
+    lib = hk.load_test_library()
     try:
         good = m.infer([list(ids[0])], [list(styles[0])], 1.0, seed=4, flags=hk.KX_FLAG_TAPS)
         good_taps = {n: m.tap(n, 0).copy() for n in names}
-        lib = hk.load_test_library()
+        assert m.status() == [0, 0, 0, 0]
         assert lib.kx_test_lstm_fault(6) != 0, "the fault hook must not arm outside a test process (KX_TEST_HOOKS unset)"
         os.environ["KX_TEST_HOOKS"] = "1"
-        assert lib.kx_test_lstm_fault(6) == 0  # the sixth LSTM of a forward = predictor.shared, over the frame axis
         try:
-            with pytest.raises(hk.KokoroxHipError) as ei:
+            # (1) host path, the sixth recurrence of the forward = predictor.shared over the frame axis, after the mid-way check
+            assert lib.kx_test_lstm_fault(6) == 0
+            out = m.infer([list(ids[0])], [list(styles[0])], 1.0, seed=4)
+            np.testing.assert_array_equal(out, good)
+            assert m.status() == [1, 1, 63, 1], m.status()
+            lib.kx_test_lstm_fault(0)
+            # (2) the streaming recurrence from here on: every tap and the waveform bit for bit
+            again = m.infer([list(ids[0])], [list(styles[0])], 1.0, seed=4, flags=hk.KX_FLAG_TAPS)
+            np.testing.assert_array_equal(again, good)
+            for n in names:
+                np.testing.assert_array_equal(m.tap(n, 0), good_taps[n])
+            # (3) the resident forms return after 64 clean forwards
+            for _ in range(62):
                 m.infer([list(ids[0])], [list(styles[0])], 1.0, seed=4)
+            assert m.status() == [0, 1, 0, 1], m.status()
+            np.testing.assert_array_equal(m.infer([list(ids[0])], [list(styles[0])], 1.0, seed=4), good)
+            # (4) device-pointer path
+            dev = torch.device("cuda:0")
+            T = len(ids[0])
+            d_ids = torch.tensor([list(ids[0])], dtype=torch.int64, device=dev)
+            d_st = torch.tensor(np.asarray([styles[0]], dtype=np.float32), device=dev)
+            d_audio = torch.zeros((1, good.shape[0]), dtype=torch.float32, device=dev)
+            d_fr = torch.zeros(1, dtype=torch.int32, device=dev)
+            lens = np.array([T], dtype=np.int32)
+            torch.cuda.synchronize()
+            assert lib.kx_test_lstm_fault(2) == 0  # a token-axis recurrence: re-run inside kx_infer_device
+            m.infer_device(d_ids.data_ptr(), T, lens, d_st.data_ptr(), np.array([1.0], dtype=np.float32), d_audio.data_ptr(), good.shape[0],
+                           d_fr.data_ptr(), seed=4)
+            lib.kx_test_lstm_fault(0)
+            m.sync()
+            np.testing.assert_array_equal(d_audio[0].cpu().numpy(), good)
+            st = m.status()
+            assert st[0] == 1 and st[1] == 2 and st[3] == 2, st
+            # ... and the frame-axis one: the call cannot be repeated from kx_sync, which must fail
+            for _ in range(64):
+                m.infer([list(ids[0])], [list(styles[0])], 1.0, seed=4)
+            assert m.status()[0] == 0
+            assert lib.kx_test_lstm_fault(6) == 0
+            m.infer_device(d_ids.data_ptr(), T, lens, d_st.data_ptr(), np.array([1.0], dtype=np.float32), d_audio.data_ptr(), good.shape[0],
+                           d_fr.data_ptr(), seed=4)
+            with pytest.raises(hk.KokoroxHipError) as ei:
+                m.sync()
             assert "LSTM" in str(ei.value)
+            lib.kx_test_lstm_fault(0)
+            np.testing.assert_array_equal(m.infer([list(ids[0])], [list(styles[0])], 1.0, seed=4), good)
         finally:
             lib.kx_test_lstm_fault(0)
             del os.environ["KX_TEST_HOOKS"]
-        again = m.infer([list(ids[0])], [list(styles[0])], 1.0, seed=4, flags=hk.KX_FLAG_TAPS)
-        # The one-CU kernel adds in its own order, so results after the fall-back are NOT bit-identical to the two-CU
-        # kernel's (include/kokorox_hip.h says so): every recurrence output and what is computed from it must agree to
-        # rounding; the waveform itself only in form, because a last-bit change of the F0 curve moves the harmonic phases
-        # (DESIGN.md section 4).
-        assert again.shape == good.shape and np.isfinite(again).all() and np.abs(again).max() < 10 * np.abs(good).max()
-        for n in names:
-            ref = good_taps[n]
-            assert np.abs(m.tap(n, 0) - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max()), n
     finally:
         m.close()
 

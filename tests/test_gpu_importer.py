@@ -150,31 +150,39 @@ def test_onnx_cache_replicas_and_error_paths(blob_path, tmp_path, monkeypatch):
         for m in ms:
             m.close()
     np.testing.assert_array_equal(a, b)
-    # opt-in cache: written beside the .onnx, then used (a cache that is older than the .onnx is ignored)
+    # opt-in cache (KOKOROX_KXW_CACHE=1): written beside the .onnx with a stamp naming the source's size, mtime (ns) and the
+    # importer's version; consulted only under the same switch and only while the stamp matches exactly
     monkeypatch.setenv("KOKOROX_KXW_CACHE", "1")
     m = hk.HipKoko.new(src)
     m.close()
     cache = src + ".kxw"
-    assert os.path.exists(cache)
-    monkeypatch.delenv("KOKOROX_KXW_CACHE")
+    assert os.path.exists(cache) and os.path.exists(cache + ".src")
     py = str(tmp_path / "py.kxw")
     from kokorox_amd import importer as I
     I.import_onnx(src, py)
     assert open(cache, "rb").read() == open(py, "rb").read()
-    # poison the .onnx but keep it older than the cache: the cache is what loads
-    onnx_bytes = open(src, "rb").read()
-    t = os.path.getmtime(cache)
+    # corrupt the .onnx but keep its size and mtime: the stamp still matches, the cache is what loads
+    st = os.stat(src)
+    onnx_bytes = bytearray(open(src, "rb").read())
+    onnx_bytes[0:64] = b"\xff" * 64  # (the ModelProto's first fields: no longer parseable)
     with open(src, "wb") as f:
-        f.write(onnx_bytes[: len(onnx_bytes) // 3])
-    os.utime(src, (t - 10, t - 10))
+        f.write(onnx_bytes)
+    os.utime(src, ns=(st.st_atime_ns, st.st_mtime_ns))
     m = hk.HipKoko.new(src)
     try:
         np.testing.assert_array_equal(m.infer([list(ids)], [list(style_row)], 1.0, seed=1), a)
     finally:
         m.close()
-    # a newer (still truncated) .onnx invalidates the cache: KX_ERR_IO class failure, message from the reader
-    os.utime(src, (t + 10, t + 10))
-    with pytest.raises(RuntimeError, match="not a readable ONNX model.*truncated"):
+    # without the switch a cache file is never trusted, however new: the (corrupt) .onnx is read
+    monkeypatch.delenv("KOKOROX_KXW_CACHE")
+    with pytest.raises(RuntimeError, match="not a readable ONNX model|ONNX"):
         hk.HipKoko.new(src)
+    # with the switch, a source whose mtime moved -- EARLIER, as cp -p / mv / a re-pointed blob symlink leave it -- no longer
+    # matches the stamp: the cache is ignored (a "cache not older than the source" test would have loaded it)
+    monkeypatch.setenv("KOKOROX_KXW_CACHE", "1")
+    os.utime(src, ns=(st.st_atime_ns, st.st_mtime_ns - 10_000_000_000))
+    with pytest.raises(RuntimeError, match="not a readable ONNX model|ONNX"):
+        hk.HipKoko.new(src)
+    monkeypatch.delenv("KOKOROX_KXW_CACHE")
     with pytest.raises(RuntimeError, match="not a readable ONNX model"):
         hk.HipKoko.replicas(src, [0, 0])

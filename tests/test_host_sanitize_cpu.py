@@ -30,3 +30,19 @@ def test_dispatcher_and_api_guard_under_sanitizers(tmp_path, name, flags, env):
         r = subprocess.run([exe], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "scenarios passed" in r.stdout, r.stdout[-1000:] + r.stderr[-6000:]
         assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr
+
+
+def test_dispatcher_queue_throughput_with_zero_cost_models(tmp_path):
+    """What the dispatcher's host side can move per second when the forwards cost nothing: 64 client threads in front of 8 stub
+    models (optimised build, no sanitizer).  The 8-GPU server of BASELINE configs[4] needs 8 x ~555 requests/s at the per-GPU
+    rate measured on one MI355X: the queue must not be what caps it.  The number is printed for DESIGN.md."""
+    exe = str(tmp_path / "host_throughput")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "kokorox_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "cpp", "host_sanitize.cpp"), "-o", exe, "-lpthread"], check=True)
+    r = subprocess.run([exe, "throughput"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    import re
+    m = re.search(r"throughput: (\d+) requests/s", r.stdout)
+    assert m, r.stdout
+    print(r.stdout.strip())
+    assert int(m.group(1)) >= 5000, r.stdout
