@@ -405,9 +405,8 @@ def main():
                     help="free = the timed steps run on the predicted (ragged) durations: a profiling mode (rocprof of the "
                          "ragged step, tools/ragged_profile.sh); the headline is the pinned workload")
     ap.add_argument("--serve-models", type=int, default=1,
-                    help="models per GPU behind the serving leg's dispatcher (1: the dispatcher already keeps the next batch's "
-                         "forward behind the current one with two workers per model; several models on one GPU take turns forward by "
-                         "forward and come out 9 %% slower, DESIGN.md section 7)")
+                    help="models per GPU behind the serving leg's dispatcher: n > 1 = n CU-partitioned models (kx_create_replicas with the "
+                         "device id given n times: each confined to 1 / n of the CUs, forwards side by side; DESIGN.md section 7)")
     ap.add_argument("--latency-b1", type=int, default=50, help="batch-1 calls timed for the latency_b1 block (configs[1]; 0 = skip)")
     ap.add_argument("--replicas", type=int, default=0,
                     help="single-process form: N models from kx_create_replicas, one host thread each (instead of torchrun)")
@@ -711,12 +710,17 @@ def main():
         }
         out["serve"] = None
         if world == 1 and a.serve:
-            serve_models = [model] + [hk.HipKoko.new(blob_path, device=dev_index) for _ in range(max(0, a.serve_models - 1))]
+            if a.serve_models > 1:
+                # several models on the one GPU: CU-partitioned (each confined to 1 / n of the CUs, forwards side by side)
+                serve_models = hk.HipKoko.replicas(blob_path, [dev_index] * a.serve_models)
+            else:
+                serve_models = [model]
             try:
                 out["serve"] = serve_leg(serve_models)
             finally:
-                for m2 in serve_models[1:]:
-                    m2.close()
+                if a.serve_models > 1:
+                    for m2 in serve_models:
+                        m2.close()
         if world == 1 and a.cpu_utts > 0:
             out["cpu_baseline"] = cpu_baseline(blob_path, a.cpu_utts, a.phonemes, pinned)
         else:

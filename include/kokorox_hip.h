@@ -72,12 +72,25 @@ kx_model* kx_create_from_device_blob(const void* d_blob, size_t n_bytes, int dev
 /* One model per GPU for the server (the reference's server is ONE process, kokorox-openai/src/lib.rs:
  * 370-439): reads the weight file ONCE (`.onnx` or container, as kx_create), uploads it to device_ids[0] over PCIe and fans it out to the other
  * devices with concurrent device-to-device copies (hipMemcpyPeerAsync, one xGMI link per destination), then builds
- * every model from its resident blob.  out_models[n] receives the handles, ready for kx_dispatcher_create; ids may
- * repeat (several models on one GPU).  On failure nothing is leaked and every entry of out_models is NULL.
+ * every model from its resident blob, the models side by side (one host thread each).  out_models[n] receives the handles,
+ * ready for kx_dispatcher_create.  A device id that is given k times (k <= 8) gets k CU-PARTITIONED models, each confined to
+ * 1 / k of the device's CUs (kx_create_partition): they run their forwards side by side on the one GPU and never compete for a
+ * CU (KX_REPLICA_PARTITION=0: whole-device models that take turns instead).  On failure nothing is leaked and every entry of
+ * out_models is NULL.
  * (A multi-PROCESS launch — one rank per GPU, as bench.py under torch.distributed — uses an RCCL broadcast of the
  * blob and kx_create_from_device_blob instead: kokorox_amd/dist.py.) */
 int kx_create_replicas(const char* weights_path, const int* device_ids, int n, kx_model** out_models, char* err,
                        size_t err_len);
+/* Milestones of the process's last kx_create_replicas call, ms from its entry: out3[0] weight file read (and, for an .onnx,
+ * converted), [1] blob resident on every device (PCIe upload + the fan-out copies), [2] every model built. */
+int kx_replicas_times(double* out3);
+
+/* A model confined to CUs [part, part + 1) x CUs / n_parts of the device (n_parts 1 .. 8; n_parts = 1 is kx_create): every
+ * stream of the model carries that CU mask (hipExtStreamCreateWithCUMask; the driver deals the bits over the XCCs, so a
+ * partition keeps its share of every XCC's L2).  Models with disjoint partitions run concurrently on one GPU with no
+ * contention for CUs -- two forwards in flight per GPU behind one dispatcher -- and give the bits of a whole-device model.
+ * No reference counterpart (one Mutex<Session> per process, ort_koko.rs:78). */
+kx_model* kx_create_partition(const char* weights_path, int device_id, int part, int n_parts, char* err, size_t err_len);
 
 /* Replaces `Drop for OrtKoko` / TTSKoko::cleanup (kokorox/src/tts/koko.rs:1338-1375). */
 void kx_destroy(kx_model* m);

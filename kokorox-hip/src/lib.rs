@@ -49,6 +49,9 @@ extern "C" {
                                   err_len: usize) -> *mut KxModel;
     fn kx_create_replicas(weights_path: *const c_char, device_ids: *const c_int, n: c_int,
                           out_models: *mut *mut KxModel, err: *mut c_char, err_len: usize) -> c_int;
+    fn kx_replicas_times(out3: *mut f64) -> c_int;
+    fn kx_create_partition(weights_path: *const c_char, device_id: c_int, part: c_int, n_parts: c_int,
+                           err: *mut c_char, err_len: usize) -> *mut KxModel;
     fn kx_destroy(m: *mut KxModel);
     fn kx_last_error(m: *const KxModel) -> *const c_char;
     fn kx_last_error_copy(m: *const KxModel, buf: *mut c_char, buf_len: usize) -> c_int;

@@ -3,6 +3,9 @@
 #include <cstring>
 #include <memory>
 #include <vector>
+#include <thread>
+#include <chrono>
+#include <mutex>
 
 #include "../../include/kokorox_hip.h"
 #include "model.h"
@@ -77,6 +80,27 @@ kx_model* kx_create_from_device_blob(const void* d_blob, size_t n_bytes, int dev
     return rc == KX_OK ? h : nullptr;
 }
 
+static std::mutex g_replica_times_mu;
+static double g_replica_times[3] = {0, 0, 0};
+
+int kx_replicas_times(double* out3) {
+    if (!out3) return KX_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(g_replica_times_mu);
+    for (int i = 0; i < 3; ++i) out3[i] = g_replica_times[i];
+    return KX_OK;
+}
+
+kx_model* kx_create_partition(const char* weights_path, int device_id, int part, int n_parts, char* err, size_t err_len) {
+    kx_model* h = nullptr;
+    int rc = guarded_free(err, err_len, [&] {
+        check_device(device_id);
+        std::unique_ptr<Model> m(new Model(device_id, part, n_parts));
+        m->load_file(weights_path);
+        h = new kx_model{std::move(m)};
+    });
+    return rc == KX_OK ? h : nullptr;
+}
+
 int kx_create_replicas(const char* weights_path, const int* device_ids, int n, kx_model** out_models, char* err,
                        size_t err_len) {
     if (out_models)
@@ -85,11 +109,16 @@ int kx_create_replicas(const char* weights_path, const int* device_ids, int n, k
     std::vector<int> blob_dev;
     std::vector<hipStream_t> streams;
     std::vector<kx_model*> made;
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t0 = clk::now();
+    auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+    double t_ms[3] = {0, 0, 0};  // file read (+ conversion) done, fan-out done, models built
     int rc = guarded_free(err, err_len, [&] {
         KX_REQUIRE(device_ids && out_models && n >= 1 && n <= 64, "create_replicas: 1..64 device ids and an output array");
         for (int i = 0; i < n; ++i) check_device(device_ids[i]);
         const std::vector<unsigned char> host = kx::read_weight_file(weights_path);  // the ONE file read
         const size_t nb = host.size();
+        t_ms[0] = ms_since(t0);
         blobs.assign(n, nullptr);
         blob_dev.assign(device_ids, device_ids + n);
         streams.assign(n, nullptr);
@@ -116,15 +145,56 @@ int kx_create_replicas(const char* weights_path, const int* device_ids, int n, k
             KX_HIP(hipSetDevice(device_ids[i]));
             KX_HIP(hipStreamSynchronize(streams[i]));
         }
-        for (int i = 0; i < n; ++i) {
-            std::unique_ptr<Model> m(new Model(device_ids[i]));
-            void* b = blobs[i];
-            blobs[i] = nullptr;  // the model owns it from here on (freed by its destructor, also on a failed build)
-            m->adopt_blob_guard(b);
-            m->load_device_blob(b, nb, /*adopt=*/true);
-            made.push_back(new kx_model{std::move(m)});
-        }
+        t_ms[1] = ms_since(t0);
+        // A device id that is given k times gets k CU-partitioned models (each confined to 1 / k of the CUs: they run side by
+        // side without competing for a CU -- Model::Model); KX_REPLICA_PARTITION=0: whole-device models that take turns.
+        static const bool partition = !(getenv("KX_REPLICA_PARTITION") && atoi(getenv("KX_REPLICA_PARTITION")) == 0);
+        std::vector<int> part(n, 0), parts(n, 1);
+        if (partition)
+            for (int i = 0; i < n; ++i) {
+                int k = 0, j = 0;
+                for (int q = 0; q < n; ++q) {
+                    if (device_ids[q] != device_ids[i]) continue;
+                    if (q < i) ++j;
+                    ++k;
+                }
+                KX_REQUIRE(k <= 8, "create_replicas: at most 8 models per device");
+                part[i] = j;
+                parts[i] = k;
+            }
+        // the models are built side by side, one host thread each (weight repacking on the model's own GPU and stream)
+        made.assign(n, nullptr);
+        std::vector<std::string> build_err(n);
+        std::vector<int> build_rc(n, KX_OK);
+        std::vector<std::thread> th;
+        for (int i = 0; i < n; ++i)
+            th.emplace_back([&, i] {
+                void* b = blobs[i];
+                try {
+                    std::unique_ptr<Model> m(new Model(device_ids[i], part[i], parts[i]));
+                    blobs[i] = nullptr;  // the model owns it from here on (freed by its destructor, also on a failed build)
+                    m->adopt_blob_guard(b);
+                    if (getenv("KX_TEST_HOOKS") && getenv("KX_TEST_FAIL_REPLICA") && atoi(getenv("KX_TEST_FAIL_REPLICA")) == i)
+                        throw Error(KX_ERR_IO, "create_replicas: injected failure of replica " + std::to_string(i) + " (KX_TEST_FAIL_REPLICA)");
+                    m->load_device_blob(b, nb, /*adopt=*/true);
+                    made[i] = new kx_model{std::move(m)};
+                } catch (const Error& e) {
+                    build_rc[i] = e.code;
+                    build_err[i] = e.what();
+                } catch (const std::exception& e) {
+                    build_rc[i] = KX_ERR_DEVICE;
+                    build_err[i] = e.what();
+                }
+            });
+        for (std::thread& t : th) t.join();
+        t_ms[2] = ms_since(t0);
+        for (int i = 0; i < n; ++i)
+            if (build_rc[i] != KX_OK) throw Error(build_rc[i], "create_replicas: replica " + std::to_string(i) + ": " + build_err[i]);
     });
+    {
+        std::lock_guard<std::mutex> lk(g_replica_times_mu);
+        for (int i = 0; i < 3; ++i) g_replica_times[i] = t_ms[i];
+    }
     for (size_t i = 0; i < streams.size(); ++i)
         if (streams[i]) {
             (void)hipSetDevice(blob_dev[i]);
@@ -136,7 +206,8 @@ int kx_create_replicas(const char* weights_path, const int* device_ids, int n, k
             (void)hipFree(blobs[i]);
         }
     if (rc != KX_OK) {
-        for (kx_model* h : made) kx_destroy(h);
+        for (kx_model* h : made)
+            if (h) kx_destroy(h);
         return rc;
     }
     for (int i = 0; i < n; ++i) out_models[i] = made[i];

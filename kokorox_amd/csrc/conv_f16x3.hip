@@ -375,6 +375,7 @@ static int env_int(const char* name, int dflt) {
 }
 
 int conv16_cu_count() {  // of the CURRENT device (cached per device: models on several GPUs launch from several threads)
+    if (const int part = cu_count_override()) return part;  // (a CU-partitioned model is launching: its share)
     static std::atomic<int> n[KX_MAX_DEVICES];
     int dev = 0;
     KX_HIP(hipGetDevice(&dev));

@@ -184,7 +184,8 @@ void launch_conv1d_f16x3_da(const ConvArgs& a, int B, int max_cols, hipStream_t 
 bool conv16_use_dag(const ConvArgs& a, int BM);       // eligible AND switched on (default; KX_DAG=0 turns it off)
 bool conv16_dag_eligible(const ConvArgs& a, int BM);
 void launch_conv1d_f16x3_dag(const ConvArgs& a, int B, int max_cols, hipStream_t s);
-int conv16_cu_count();  // CUs of the current device (conv_f16x3.hip)
+int conv16_cu_count();  // CUs of the current device, or of the launching model's CU partition (conv_f16x3.hip)
+int cu_count_override(); // model.hip: the CU partition of the model that is launching on this thread (0 = none)
 // shapes that take the 16x16x32 form of the direct-A conv (conv_f16x3_da_s16.hip): 192 / 128-column tiles, 64-column statistics slots
 bool conv16_da_s16_shape(int BM, int K, int dil, int stride, int act, int n_chunks16, bool merged, bool prec1);
 size_t packed_conv16_halves(int rows, int Cin, int K, int BM);

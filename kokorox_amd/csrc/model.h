@@ -101,7 +101,7 @@ struct LstmTimeout : Error {
 
 class Model {
   public:
-    Model(int device);
+    Model(int device, int part = 0, int n_parts = 1);  // n_parts > 1: confined to CUs [part, part + 1) x CUs / n_parts
     ~Model();
     void load_file(const char* path);
     void load_device_blob(const void* d_blob, size_t n, bool adopt = false);
@@ -164,6 +164,7 @@ class Model {
     int get_act_shift(const std::string& conv_name) const;
     const Tap* find_tap(const std::string& name) const;
 
+    int cu_partition(int* n_parts) const { *n_parts = n_parts_; return part_; }
     std::mutex mu;
     uint64_t utt_base = 0;
     void set_lanes(int n) { lanes_cfg_ = n < 0 ? 0 : (n > N_LANES ? N_LANES : n); }
@@ -215,6 +216,9 @@ class Model {
     struct DeviceTurn;                      // one forward at a time per GPU across models (model.hip)
     void sync_lanes();
 
+    int part_ = 0, n_parts_ = 1, cu_count_ = 0;  // cu_count_ = 0: the whole device
+    std::vector<uint32_t> cu_mask_;
+    void new_stream(hipStream_t* s);
     hipStream_t stream_ = nullptr;
     // side stream for the TextEncoder branch, which does not depend on the ALBERT / duration branch
     hipStream_t stream2_ = nullptr;

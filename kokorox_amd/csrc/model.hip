@@ -19,7 +19,16 @@ static constexpr float RSQRT2 = 0.70710678118654752f;
 // 128-byte line (arenas are 256-byte aligned)
 static inline int up4(int x) { return (x + 31) & ~31; }
 
-Model::Model(int dev) : device(dev) {
+// CUs of the launches this thread is issuing: the device's, or the model's share of them (CU-partitioned models)
+static thread_local int tl_cu_override = 0;
+int cu_count_override() { return tl_cu_override; }
+struct CuScope {
+    int saved;
+    explicit CuScope(int n) : saved(tl_cu_override) { tl_cu_override = n; }
+    ~CuScope() { tl_cu_override = saved; }
+};
+
+Model::Model(int dev, int part, int n_parts) : device(dev), part_(part), n_parts_(n_parts) {
     if (const char* e = getenv("KOKOROX_CONV"))
         conv_mode = (strcmp(e, "f32") == 0) ? CONV_F32 : (strcmp(e, "f16") == 0 ? CONV_F16 : CONV_F16X3);
     if (const char* e = getenv("KOKOROX_STFT")) stft_variant = (strcmp(e, "torch") == 0) ? STFT_TORCH : STFT_ONNX;
@@ -31,7 +40,25 @@ Model::Model(int dev) : device(dev) {
     // another model on the same GPU (two models per GPU in the server, kx_create_replicas with repeated ids).  Everything
     // on the forward's path is issued on stream_ or ordered to it by events; kx_infer_device orders its device inputs
     // after the caller's null-stream work explicitly (infer_device_after_null).
-    KX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    // A CU-partitioned model (kx_create_partition; kx_create_replicas with a device id given k times): every stream of the model
+    // is confined to its share of the CUs -- bits [part, part + 1) x CUs / n_parts of the queue's CU mask, which the driver deals
+    // over the XCCs (probed: either half of the bits is 128 CUs on all 8 XCCs) -- so k models run their forwards side by side
+    // on one GPU without ever competing for a CU: a recurrence's workgroups, which need a whole CU each, cannot starve behind
+    // another model's conv workgroups (profiles/r04_serve_models_per_gpu.txt), and the under-filled phases of one forward (the
+    // token-axis front half, the recurrences) run beside the other's convs.  (Such streams synchronise with the legacy null
+    // stream -- the extension has no flags argument; nothing on the forward's path touches that stream.)
+    KX_REQUIRE(n_parts >= 1 && n_parts <= 8 && part >= 0 && part < n_parts, "model: partition must be 0 .. n_parts - 1 of 1 .. 8");
+    if (n_parts > 1) {
+        hipDeviceProp_t prop;
+        KX_HIP(hipGetDeviceProperties(&prop, device));
+        const int cus = prop.multiProcessorCount;
+        const int lo = (int)((long)cus * part / n_parts), hi = (int)((long)cus * (part + 1) / n_parts);
+        KX_REQUIRE(hi - lo >= 16, "model: a partition needs at least 16 CUs");
+        cu_mask_.assign((size_t)(cus + 31) / 32, 0u);
+        for (int i = lo; i < hi; ++i) cu_mask_[(size_t)i >> 5] |= 1u << (i & 31);
+        cu_count_ = hi - lo;
+    }
+    new_stream(&stream_);
     main_stream_ = stream_;
     KX_HIP(hipMalloc((void**)&d_dev_err_, sizeof(unsigned)));
     KX_HIP(hipMemsetAsync(d_dev_err_, 0, sizeof(unsigned), stream_));
@@ -39,13 +66,18 @@ Model::Model(int dev) : device(dev) {
     memset(h_words_, 0, 8 * sizeof(unsigned));
     KX_HIP(hipEventCreateWithFlags(&ev_null_, hipEventDisableTiming));
     KX_HIP(hipStreamSynchronize(stream_));
-    KX_HIP(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+    new_stream(&stream2_);
     lanes_[0].stream = stream_;
-    for (int i = 1; i < N_LANES; ++i) KX_HIP(hipStreamCreateWithFlags(&lanes_[i].stream, hipStreamNonBlocking));
+    for (int i = 1; i < N_LANES; ++i) new_stream(&lanes_[i].stream);
     if (const char* e = getenv("KX_LANES")) set_lanes(atoi(e));
     KX_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     KX_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     init_dft_tables();
+}
+
+void Model::new_stream(hipStream_t* s) {
+    if (cu_mask_.empty()) KX_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    else KX_HIP(hipExtStreamCreateWithCUMask(s, (uint32_t)cu_mask_.size(), cu_mask_.data()));
 }
 
 Model::~Model() {
@@ -1104,7 +1136,8 @@ struct Model::DeviceTurn {
     DeviceGate& g;
     std::unique_lock<std::mutex> lk;
     const bool on;
-    explicit DeviceTurn(Model& mm) : m(mm), g(device_gate(mm.device)), lk(g.mu, std::defer_lock), on(device_turn_on()) {
+    // (CU-partitioned models never compete for a CU: they do not take turns)
+    explicit DeviceTurn(Model& mm) : m(mm), g(device_gate(mm.device)), lk(g.mu, std::defer_lock), on(device_turn_on() && mm.n_parts_ == 1) {
         if (!on) return;
         lk.lock();
         if (g.last && g.owner != &m) KX_HIP(hipStreamWaitEvent(m.main_stream_, g.last, 0));
@@ -1131,6 +1164,7 @@ void Model::infer_device(const int64_t* d_ids, int64_t t_stride, const int32_t* 
     }
     for (int i = 0; i < n_speed; ++i) KX_REQUIRE(speeds_host[i] > 0.f, "infer: speed must be > 0");
     KX_HIP(hipSetDevice(device));
+    CuScope cu_scope(cu_count_);  // (grid heuristics of the launchers: this model's CUs)
     using clk = std::chrono::steady_clock;
     const clk::time_point t_enter = clk::now();
     auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };

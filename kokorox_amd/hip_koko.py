@@ -81,6 +81,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_last_error": (cp, [vp]),
         "kx_last_error_copy": (i32, [vp, cp, sz]),
         "kx_create_replicas": (i32, [cp, vp, i32, vp, cp, sz]),
+        "kx_replicas_times": (i32, [C.POINTER(C.c_double)]),
+        "kx_create_partition": (vp, [cp, i32, i32, i32, cp, sz]),
         "kx_infer": (i32, [vp, vp, i64, vp, i32, vp, vp, i32, u64, u32, C.POINTER(C.POINTER(f32)), vp]),
         "kx_free_audio": (None, [C.POINTER(f32)]),
         "kx_infer_device": (i32, [vp, vp, i64, vp, i32, vp, vp, i32, u64, u32, vp, i64, vp, C.POINTER(i64)]),
@@ -166,7 +168,7 @@ TEST_ABI_SYMBOLS = ["kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test
                     "kx_test_conv_transpose", "kx_test_lstm_fault", "kx_test_lstm_parts"]
 
 ABI_SYMBOLS = [
-    "kx_version", "kx_init", "kx_create", "kx_import_onnx", "kx_create_from_device_blob", "kx_create_replicas", "kx_destroy",
+    "kx_version", "kx_init", "kx_create", "kx_import_onnx", "kx_create_from_device_blob", "kx_create_replicas", "kx_replicas_times", "kx_create_partition", "kx_destroy",
     "kx_last_error", "kx_last_error_copy", "kx_infer",
     "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_warmup", "kx_arena_bytes", "kx_call_times", "kx_model_status", "kx_dispatcher_health", "kx_set_utterance_base", "kx_set_lanes",
     "kx_set_conv_mode", "kx_get_conv_mode", "kx_set_stft_variant", "kx_get_stft_variant",
@@ -230,6 +232,23 @@ class HipKoko:
         if rc != 0:
             raise RuntimeError(f"Failed to create Kokoro TTS model: {err.value.decode()}")
         return [cls("", int(d), _handle=out[i]) for i, d in enumerate(dev)]
+
+    @staticmethod
+    def replicas_times():
+        """ms from the last `replicas` call's entry: [file read (+ conversion), blob resident on every device, models built]."""
+        out = (C.c_double * 3)()
+        load_library().kx_replicas_times(out)
+        return list(out)
+
+    @classmethod
+    def partition(cls, model_path: str, device: int, part: int, n_parts: int) -> "HipKoko":
+        """A model confined to 1 / n_parts of the device's CUs (kx_create_partition): partitions run side by side on one GPU."""
+        lib = load_library()
+        err = C.create_string_buffer(512)
+        h = lib.kx_create_partition(os.fsencode(model_path), device, part, n_parts, err, len(err))
+        if not h:
+            raise RuntimeError(f"Failed to create Kokoro TTS model: {err.value.decode()}")
+        return cls("", device, _handle=h)
 
     def last_error(self) -> str:
         """Thread-safe copy of the model's last failure text (kx_last_error_copy)."""

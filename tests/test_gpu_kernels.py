@@ -4,10 +4,14 @@ Both contraction modes are covered: f32 MFMA (a k-ordered fmaf chain, error ~1e-
 f16x3 split MFMA (three f16 MFMAs per step on hi/lo halves, ~2^-22 per product).  2e-5 absolute on
 O(1) outputs with K up to 3270 leaves margin for both.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -148,46 +152,31 @@ def test_bilstm_more_pairs_than_cus():
         assert np.abs(y - ref).max() < 1e-5
 
 
-def test_two_models_run_full_size_forwards_side_by_side(blob_path):
-    """Two models on one GPU, each running batch-32 forwards of 128-phoneme utterances from its own thread.  Left to run side
-    by side their kernels contend for CUs and a half of the two-CU LSTM can starve behind the other model's conv workgroups
-    until its partner's bounded poll gives up (round 4 measured exactly that once the streams became non-blocking: a 1 - 2 s
-    stall, KX_ERR_DEVICE, fall-back to the one-CU kernel whose bits differ).  The forwards of the models of one device
-    therefore take turns (Model::DeviceTurn): no call may fail, and both must equal the result of a quiet run bit for bit."""
-    import threading
-    from kokorox_amd import hip_koko as hk
-    from kokorox_amd import weights as W
-    from oracle import kokoro_ref as R
-    B, n_ph = 32, 128
-    toks = [list(R.synthetic_inputs(1, n_ph, seed=900 + i)[0]) for i in range(B)]
-    voices = W.synthetic_voices(4)
-    styles = [voices[i % 4, n_ph, 0] for i in range(B)]
-    ms = hk.HipKoko.replicas(blob_path, [0, 0])
-    try:
-        for m in ms:
-            m.set_pinned_durations([3, 3, 3, 4])
-        quiet = ms[0].infer_batch(toks, styles, [1.0], seed=11)
-        res, errs = [None, None], []
-
-        def run(i):
-            try:
-                for _ in range(3):
-                    res[i] = ms[i].infer_batch(toks, styles, [1.0], seed=11)
-            except Exception as e:  # pragma: no cover
-                errs.append(e)
-
-        th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join(timeout=600)
-        assert not errs, errs
-        for i in range(2):
-            for a, b in zip(res[i], quiet):
-                np.testing.assert_array_equal(a, b)
-    finally:
-        for m in ms:
-            m.close()
+@pytest.mark.parametrize("mode,turn", [("partition", "1"), ("whole", "1"), ("whole", "0")])
+def test_two_models_run_full_size_forwards_side_by_side(blob_path, mode, turn):
+    """Two models on one GPU, each running batch-32 forwards of 128-phoneme utterances from its own thread (tools/
+    two_models_side_by_side.py, a process of its own: the switches are read once).  No call may fail and every result must equal
+    a quiet run bit for bit, in all three arrangements:
+      partition      kx_create_replicas with the device id given twice: two CU-partitioned models (round 5), each confined to
+                     half of the CUs -- side by side, never competing for a CU;
+      whole, turn 1  two whole-device models: their forwards take turns (Model::DeviceTurn, round 4);
+      whole, turn 0  two whole-device models left to run side by side (KX_DEVICE_TURN=0): a recurrence's workgroups, which need a
+                     whole CU each, can starve behind the other model's conv workgroups until its partner's bounded poll gives up
+                     (round 4 measured a 1 - 2 s stall, KX_ERR_DEVICE and a fall-back whose bits differed).  Round 5: the
+                     time-out is 0.2 s, the fall-back gives the same bits and the call is re-run inside the library, so the
+                     caller sees neither an error nor a different bit; kx_model_status says what happened."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, KX_DEVICE_TURN=turn)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "two_models_side_by_side.py"), mode, "3"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    print(d)
+    assert d["ok"] and not d["errors"] and d["wrong"] == 0, d
+    if turn == "1":  # (taking turns / partitioned: nothing may even have timed out)
+        assert all(st[1] == 0 and st[3] == 0 for st in d["status"]), d
 
 
 def test_harmonic_source_phase_is_bit_faithful(oracle):
