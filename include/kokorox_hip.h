@@ -147,6 +147,18 @@ int kx_infer_device(kx_model* m, const int64_t* d_ids, int64_t t_stride, const i
 
 int kx_sync(kx_model* m);
 
+/* What was loaded and how it runs.  out8[0]: the weight file's kind -- 0 the library's KXHIPW01 container, 1 fp32 ONNX
+ * (onnx/model.onnx, hf_cache.rs:10), 2 fp16 / bf16 ONNX (model_fp16: widened to f32), 3 an 8-bit quantised ONNX variant
+ * (model_quantized / model_uint8 / model_q8f16 / model_uint8f16), 4 a 4-bit one (model_q4 / model_q4f16), -1 a cached
+ * conversion, -2 built from a device blob (kind unknown).  out8[1]: 1 = the model computes what the reference computes for
+ * this file; 0 for kinds 3 and 4: ONNX Runtime runs those as DynamicQuantizeLinear -> MatMulInteger / ConvInteger /
+ * MatMulNBits, i.e. it quantises the ACTIVATIONS at run time, while this library de-quantises the WEIGHTS at load and then
+ * runs f32-class arithmetic -- closer to the fp32 model than the reference's own output for that file, and therefore not
+ * within 1e-4 of it (a notice is printed at load; hf_cache.rs:135-144, ort_base.rs:27-33).  out8[2]: conv mode
+ * (kx_get_conv_mode); [3] rows of the embedding tables; [4] voices in the device table; [5] / [6] CU partition and number of
+ * partitions (kx_create_partition; 0 / 1 = the whole device); [7] CUs the model launches on. */
+int kx_model_info(kx_model* m, int64_t* out8);
+
 /* What the model's LSTM recurrences are running on, and whether anything went wrong (SURVEY 8b "Threading"; the reference has
  * nothing to report: one Mutex<Session>, ort_koko.rs:78).  out4[0]: 0 = the resident-weights forms (two / four workgroups per
  * utterance and direction, which hand h over between CUs), 1 = the streaming fall-back (one workgroup, no hand-off); out4[1]:
@@ -284,6 +296,11 @@ void kx_free_packed(void* p);
 typedef struct kx_dispatcher kx_dispatcher;
 kx_dispatcher* kx_dispatcher_create(kx_model** models, int n_models, int max_batch, int max_wait_us, char* err,
                                     size_t err_len);
+/* The same, after one discarded forward of max_batch utterances x warm_tokens tokens at warm_frames_per_token frames per token
+ * on every model (kx_warmup, the models side by side): what a server should call, so that no request ever pays for an arena
+ * growing (a stream sync + hipFree + hipMalloc of gigabytes: a 1.3 s outlier in the round-4 soak). */
+kx_dispatcher* kx_dispatcher_create_warm(kx_model** models, int n_models, int max_batch, int max_wait_us, int warm_tokens,
+                                         int warm_frames_per_token, char* err, size_t err_len);
 /* Blocking; thread-safe.  ids = n_tokens ids incl. the two 0 pads; style = 256 floats.  *out: release with kx_free_audio
  * only (see above).  Equals kx_infer(B = 1, same seed, utterance base 0) bit for bit. */
 int kx_dispatcher_submit(kx_dispatcher* d, const int64_t* ids, int n_tokens, const float* style, float speed,

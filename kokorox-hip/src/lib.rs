@@ -67,6 +67,7 @@ extern "C" {
     fn kx_arena_bytes(m: *mut KxModel, out3: *mut i64) -> c_int;
     fn kx_call_times(m: *mut KxModel, out4: *mut f64) -> c_int;
     fn kx_model_status(m: *mut KxModel, out4: *mut i64) -> c_int;
+    fn kx_model_info(m: *mut KxModel, out8: *mut i64) -> c_int;
     fn kx_set_pinned_durations(m: *mut KxModel, pattern: *const i32, n: c_int) -> c_int;
     fn kx_set_conv_mode(m: *mut KxModel, mode: c_int) -> c_int;
     fn kx_get_conv_mode(m: *mut KxModel) -> c_int;
@@ -93,6 +94,8 @@ extern "C" {
     fn kx_free_packed(p: *mut c_void);
     fn kx_dispatcher_create(models: *mut *mut KxModel, n_models: c_int, max_batch: c_int, max_wait_us: c_int,
                             err: *mut c_char, err_len: usize) -> *mut KxDispatcher;
+    fn kx_dispatcher_create_warm(models: *mut *mut KxModel, n_models: c_int, max_batch: c_int, max_wait_us: c_int,
+                                 warm_tokens: c_int, warm_frames_per_token: c_int, err: *mut c_char, err_len: usize) -> *mut KxDispatcher;
     fn kx_dispatcher_submit(d: *mut KxDispatcher, ids: *const i64, n_tokens: c_int, style: *const f32, speed: f32,
                             seed: u64, out: *mut *mut f32, out_len: *mut i64, err: *mut c_char,
                             err_len: usize) -> c_int;

@@ -116,7 +116,8 @@ int kx_create_replicas(const char* weights_path, const int* device_ids, int n, k
     int rc = guarded_free(err, err_len, [&] {
         KX_REQUIRE(device_ids && out_models && n >= 1 && n <= 64, "create_replicas: 1..64 device ids and an output array");
         for (int i = 0; i < n; ++i) check_device(device_ids[i]);
-        const std::vector<unsigned char> host = kx::read_weight_file(weights_path);  // the ONE file read
+        int variant = -2;
+        const std::vector<unsigned char> host = kx::read_weight_file(weights_path, &variant);  // the ONE file read
         const size_t nb = host.size();
         t_ms[0] = ms_since(t0);
         blobs.assign(n, nullptr);
@@ -177,6 +178,7 @@ int kx_create_replicas(const char* weights_path, const int* device_ids, int n, k
                     if (getenv("KX_TEST_HOOKS") && getenv("KX_TEST_FAIL_REPLICA") && atoi(getenv("KX_TEST_FAIL_REPLICA")) == i)
                         throw Error(KX_ERR_IO, "create_replicas: injected failure of replica " + std::to_string(i) + " (KX_TEST_FAIL_REPLICA)");
                     m->load_device_blob(b, nb, /*adopt=*/true);
+                    m->set_source_variant(variant);
                     made[i] = new kx_model{std::move(m)};
                 } catch (const Error& e) {
                     build_rc[i] = e.code;
@@ -301,6 +303,13 @@ int kx_sync(kx_model* m) {
     return guarded(m, [&](Model& M) {
         M.sync();
         M.note_clean_forward();
+    });
+}
+
+int kx_model_info(kx_model* m, int64_t* out8) {
+    return guarded(m, [&](Model& M) {
+        KX_REQUIRE(out8, "model_info: null argument");
+        M.info(out8);
     });
 }
 

@@ -137,6 +137,39 @@ kx_dispatcher* kx_dispatcher_create(kx_model** models, int n_models, int max_bat
     }
 }
 
+kx_dispatcher* kx_dispatcher_create_warm(kx_model** models, int n_models, int max_batch, int max_wait_us, int warm_tokens,
+                                         int warm_frames_per_token, char* err, size_t err_len) {
+    if (!models || n_models < 1 || max_batch < 1 || max_batch > 4096) {
+        if (err && err_len) snprintf(err, err_len, "dispatcher: bad argument");
+        return nullptr;
+    }
+    // one discarded forward of the largest shape the deployment expects on every model, the models side by side: arenas,
+    // page-locked result buffers and tile tables exist before the first request (kx_warmup says why)
+    std::vector<std::string> werr((size_t)n_models);
+    std::vector<std::thread> th;
+    for (int i = 0; i < n_models; ++i)
+        th.emplace_back([&, i] {
+            if (!models[i] || !models[i]->m) {
+                werr[(size_t)i] = "null model";
+                return;
+            }
+            kx::Model& M = *models[i]->m;
+            std::lock_guard<std::mutex> lk(M.mu);
+            try {
+                M.warmup(max_batch, warm_tokens, warm_frames_per_token);
+            } catch (const std::exception& e) {
+                werr[(size_t)i] = e.what();
+            }
+        });
+    for (std::thread& t : th) t.join();
+    for (int i = 0; i < n_models; ++i)
+        if (!werr[(size_t)i].empty()) {
+            if (err && err_len) snprintf(err, err_len, "dispatcher: warm-up of model %d failed: %s", i, werr[(size_t)i].c_str());
+            return nullptr;
+        }
+    return kx_dispatcher_create(models, n_models, max_batch, max_wait_us, err, err_len);
+}
+
 int kx_dispatcher_submit(kx_dispatcher* d, const int64_t* ids, int n_tokens, const float* style, float speed,
                          uint64_t seed, float** out, int64_t* out_len, char* err, size_t err_len) {
     if (!d) {

@@ -90,8 +90,10 @@ struct ConvOpts {
 };
 
 // the KXHIPW01 image behind `path`: the container itself (header checked), or built from the `.onnx` the reference passes
-std::vector<unsigned char> read_weight_file(const char* path);
-std::vector<unsigned char> import_onnx_bytes(const unsigned char* data, size_t n);  // ImportError -> Error(KX_ERR_IO)
+// *variant (optional): what the file was -- 0 KXHIPW01 container, 1 fp32 ONNX, 2 fp16 / bf16 ONNX, 3 8-bit quantised ONNX,
+// 4 4-bit quantised ONNX (3, 4: weights de-quantised), -1 a cached conversion (KOKOROX_KXW_CACHE=1)
+std::vector<unsigned char> read_weight_file(const char* path, int* variant = nullptr);
+std::vector<unsigned char> import_onnx_bytes(const unsigned char* data, size_t n, int* variant = nullptr);  // ImportError -> Error(KX_ERR_IO)
 
 // (KX_ERR_DEVICE class) a part of a resident-weights LSTM recurrence timed out waiting for its partner: the call is invalid,
 // the model has switched to the streaming recurrence; host entry points re-run the call once
@@ -165,6 +167,11 @@ class Model {
     const Tap* find_tap(const std::string& name) const;
 
     int cu_partition(int* n_parts) const { *n_parts = n_parts_; return part_; }
+    // [0] source variant (read_weight_file; -2 = built from a device blob: unknown), [1] 1 = the arithmetic is the reference's for
+    // this file (fp32 / fp16 source or container), 0 = de-quantised weights run f32-class (NOT ORT's integer arithmetic),
+    // [2] conv mode, [3] vocabulary rows, [4] voices in the device table, [5] CU partition, [6] partitions, [7] CUs of the model
+    void info(int64_t out[8]) const;
+    void set_source_variant(int v) { source_variant_ = v; }
     std::mutex mu;
     uint64_t utt_base = 0;
     void set_lanes(int n) { lanes_cfg_ = n < 0 ? 0 : (n > N_LANES ? N_LANES : n); }
@@ -217,6 +224,7 @@ class Model {
     void sync_lanes();
 
     int part_ = 0, n_parts_ = 1, cu_count_ = 0;  // cu_count_ = 0: the whole device
+    int source_variant_ = -2;
     std::vector<uint32_t> cu_mask_;
     void new_stream(hipStream_t* s);
     hipStream_t stream_ = nullptr;

@@ -165,9 +165,12 @@ static std::vector<unsigned char> read_all(const char* path, const char* what) {
     return host;
 }
 
-std::vector<unsigned char> import_onnx_bytes(const unsigned char* data, size_t n) {
+std::vector<unsigned char> import_onnx_bytes(const unsigned char* data, size_t n, int* variant) {
     try {
-        return onnx_to_kxw(data, n);
+        ImportInfo info;
+        std::vector<unsigned char> blob = onnx_to_kxw(data, n, &info);
+        if (variant) *variant = info.variant();
+        return blob;
     } catch (const ImportError& e) {
         throw Error(2, std::string("weight file is not a KXHIPW01 blob (bad magic) and not a readable ONNX model: ") + e.what());
     }
@@ -177,8 +180,9 @@ std::vector<unsigned char> import_onnx_bytes(const unsigned char* data, size_t n
 // OrtKoko::new (koko.rs:570-573, hf_cache.rs:128-158) — the `.onnx` file, which is converted in memory
 // (onnx_import.cpp).  `<path>.kxw` beside an .onnx is used instead when it is at least as new as the .onnx and whole;
 // it is written only when KOKOROX_KXW_CACHE=1 (a library should not drop files into a model cache unasked).
-std::vector<unsigned char> read_weight_file(const char* path) {
+std::vector<unsigned char> read_weight_file(const char* path, int* variant) {
     KX_REQUIRE(path && *path, "kx_create: empty weights path");
+    if (variant) *variant = 0;
     std::vector<unsigned char> host = read_all(path, "weight file");
     if (is_kxw_magic(host.data(), host.size())) {
         const size_t total = check_header(host.data(), host.size());
@@ -201,12 +205,24 @@ std::vector<unsigned char> read_weight_file(const char* path) {
             const std::vector<unsigned char> st = read_all(stamp_path.c_str(), "weight cache stamp");
             if (std::string(st.begin(), st.end()) == stamp) {
                 std::vector<unsigned char> c = read_all(cache.c_str(), "weight cache");
-                if (is_kxw_magic(c.data(), c.size()) && check_header(c.data(), c.size()) == c.size()) return c;
+                if (is_kxw_magic(c.data(), c.size()) && check_header(c.data(), c.size()) == c.size()) {
+                    if (variant) *variant = -1;  // (a cached conversion: the source's kind was not looked at again)
+                    return c;
+                }
             }
         } catch (const Error&) {  // no cache, or an unreadable one, is not an error: convert
         }
     }
-    std::vector<unsigned char> blob = import_onnx_bytes(host.data(), host.size());
+    int var = 1;
+    std::vector<unsigned char> blob = import_onnx_bytes(host.data(), host.size(), &var);
+    if (variant) *variant = var;
+    if (var >= 3)
+        fprintf(stderr,
+                "kokorox-hip: %s is a %d-bit quantised ONNX variant: its weights are de-quantised at load and the model runs f32-class "
+                "arithmetic, which is NOT what ONNX Runtime computes for this file (it quantises the activations at run time: "
+                "DynamicQuantizeLinear -> MatMulInteger / ConvInteger / MatMulNBits).  Parity with the reference is claimed for "
+                "onnx/model.onnx only.\n",
+                path, var == 3 ? 8 : 4);
     if (use_cache && !stamp.empty()) {
         const std::string tmp = cache + ".tmp." + std::to_string((long)getpid());
         if (FILE* f = fopen(tmp.c_str(), "wb")) {
@@ -222,7 +238,7 @@ std::vector<unsigned char> read_weight_file(const char* path) {
 }
 
 void Model::load_file(const char* path) {
-    const std::vector<unsigned char> host = read_weight_file(path);
+    const std::vector<unsigned char> host = read_weight_file(path, &source_variant_);
     const size_t n = host.size();
     parse_table(host.data(), n, n, table_);
     KX_HIP(hipSetDevice(device));
@@ -947,6 +963,22 @@ void Model::check_dev_err() {
     throw LstmTimeout("device error word " + std::to_string(e) +
                       ": a part of the resident-weights LSTM recurrence never saw its partner; this call's result is invalid; the "
                       "model runs the streaming recurrence (same bits) for the next " + std::to_string(LSTM_REARM_AFTER) + " forwards");
+}
+
+void Model::info(int64_t out[8]) const {
+    out[0] = source_variant_;
+    out[1] = (source_variant_ == 3 || source_variant_ == 4) ? 0 : 1;
+    out[2] = conv_mode;
+    out[3] = n_vocab_;
+    out[4] = n_voices_.load(std::memory_order_acquire);
+    out[5] = part_;
+    out[6] = n_parts_;
+    int cus = cu_count_;
+    if (cus == 0) {
+        hipDeviceProp_t prop;
+        cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 0;
+    }
+    out[7] = cus;
 }
 
 void Model::status(int64_t out[4]) const {

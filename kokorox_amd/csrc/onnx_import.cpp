@@ -1106,8 +1106,27 @@ const std::vector<SpecEntry>& tensor_spec() {
     return spec;
 }
 
-std::vector<unsigned char> onnx_to_kxw(const unsigned char* data, size_t n) {
+std::vector<unsigned char> onnx_to_kxw(const unsigned char* data, size_t n, ImportInfo* info) {
     const Graph g = read_graph(Span{data, n});
+    if (info) {
+        *info = ImportInfo{};
+        for (const Tensor& t : g.inits) {
+            if (t.dtype == FLOAT || t.dtype == DOUBLE) info->n_float += 1;
+            else if (t.dtype == FLOAT16) info->n_half += 1;
+            else if (t.dtype == BFLOAT16) info->n_bfloat += 1;
+            else if (t.dtype == INT8 || t.dtype == UINT8) info->n_int8 += 1;
+        }
+        for (const Node& nd : g.nodes) {
+            if (nd.op == "MatMulInteger" || nd.op == "ConvInteger" || nd.op == "DynamicQuantizeLinear") info->n_integer_ops += 1;
+            else if (nd.op == "MatMulNBits") info->n_nbits_ops += 1;
+            else if (nd.op == "DequantizeLinear") info->n_dequant_ops += 1;
+        }
+        // (MatMulNBits stores its 4-bit blocks as uint8 initialisers: they are not "8-bit weights")
+        if (info->n_nbits_ops > 0) {
+            info->n_int4_blocks = info->n_nbits_ops;
+            info->n_int8 = info->n_int8 > 2 * info->n_nbits_ops ? info->n_int8 - 2 * info->n_nbits_ops : 0;
+        }
+    }
     Importer im(g);
     im.derive_constants();
     im.place_named();

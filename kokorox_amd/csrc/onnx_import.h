@@ -51,6 +51,24 @@ inline bool is_kxw_magic(const unsigned char* p, size_t n) {
 // ONNX ModelProto bytes -> KXHIPW01 image (byte-identical to what `python -m kokorox_amd.importer` writes).
 // Throws ImportError: malformed / truncated protobuf, external-data tensors, unsupported tensor types, tensors of the
 // table that could not be found (the message lists initialisers that were not placed), shape mismatches.
-std::vector<unsigned char> onnx_to_kxw(const unsigned char* data, size_t n);
+// What kind of file it was (hf_cache.rs:135-144 lists the reference's seven variants), from the graph's operators and the
+// initialisers' types.  ONNX Runtime executes the quantised variants as DynamicQuantizeLinear -> MatMulInteger / ConvInteger /
+// MatMulNBits, i.e. it also quantises the ACTIVATIONS at run time; this importer de-quantises the weights to f32 and the model
+// then runs f32-class arithmetic -- NOT the reference's computation for those files (kx_model_info says so).
+struct ImportInfo {
+    int n_float = 0, n_half = 0, n_bfloat = 0, n_int8 = 0, n_int4_blocks = 0;  // initialisers by storage type (int4: MatMulNBits weights)
+    int n_integer_ops = 0;      // MatMulInteger + ConvInteger + DynamicQuantizeLinear nodes
+    int n_nbits_ops = 0;        // MatMulNBits nodes
+    int n_dequant_ops = 0;      // DequantizeLinear nodes
+    // 0 = the library's own container, 1 = fp32 ONNX, 2 = fp16 / bf16 ONNX (widened), 3 = 8-bit quantised ONNX (weights
+    // de-quantised), 4 = 4-bit quantised ONNX (weights de-quantised)
+    int variant() const {
+        if (n_nbits_ops > 0 || n_int4_blocks > 0) return 4;
+        if (n_integer_ops > 0 || n_dequant_ops > 0 || n_int8 > 0) return 3;
+        if (n_half + n_bfloat > n_float) return 2;
+        return 1;
+    }
+};
+std::vector<unsigned char> onnx_to_kxw(const unsigned char* data, size_t n, ImportInfo* info = nullptr);
 
 }  // namespace kx

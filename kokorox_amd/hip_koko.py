@@ -75,6 +75,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_arena_bytes": (i32, [vp, C.POINTER(i64)]),
         "kx_call_times": (i32, [vp, C.POINTER(C.c_double)]),
         "kx_model_status": (i32, [vp, C.POINTER(i64)]),
+        "kx_model_info": (i32, [vp, C.POINTER(i64)]),
         "kx_dispatcher_health": (i32, [vp, vp, i32, C.POINTER(i64), C.POINTER(i64)]),
         "kx_create_from_device_blob": (vp, [vp, sz, i32, cp, sz]),
         "kx_destroy": (None, [vp]),
@@ -107,6 +108,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "kx_infer_packed": (i32, [vp, vp, i64, vp, i32, vp, vp, i32, u64, u32, i32, C.POINTER(vp), vp, vp]),
         "kx_free_packed": (None, [vp]),
         "kx_dispatcher_create": (vp, [vp, i32, i32, i32, cp, sz]),
+        "kx_dispatcher_create_warm": (vp, [vp, i32, i32, i32, i32, i32, cp, sz]),
         "kx_dispatcher_submit": (i32, [vp, vp, i32, vp, f32, u64, C.POINTER(C.POINTER(f32)), C.POINTER(i64), cp, sz]),
         "kx_dispatcher_submit_ex": (i32, [vp, vp, i32, vp, vp, vp, i32, f32, u64, i32, C.POINTER(vp), C.POINTER(i64),
                                           C.POINTER(i64), cp, sz]),
@@ -170,10 +172,10 @@ TEST_ABI_SYMBOLS = ["kx_test_conv1d", "kx_test_lstm", "kx_test_source", "kx_test
 ABI_SYMBOLS = [
     "kx_version", "kx_init", "kx_create", "kx_import_onnx", "kx_create_from_device_blob", "kx_create_replicas", "kx_replicas_times", "kx_create_partition", "kx_destroy",
     "kx_last_error", "kx_last_error_copy", "kx_infer",
-    "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_warmup", "kx_arena_bytes", "kx_call_times", "kx_model_status", "kx_dispatcher_health", "kx_set_utterance_base", "kx_set_lanes",
+    "kx_free_audio", "kx_infer_device", "kx_sync", "kx_set_pinned_durations", "kx_warmup", "kx_arena_bytes", "kx_call_times", "kx_model_status", "kx_model_info", "kx_dispatcher_health", "kx_set_utterance_base", "kx_set_lanes",
     "kx_set_conv_mode", "kx_get_conv_mode", "kx_set_stft_variant", "kx_get_stft_variant",
     "kx_profile_enable", "kx_profile_read", "kx_profile_detail", "kx_profile_aux", "kx_diag_enable", "kx_diag_count", "kx_diag_get", "kx_set_act_prescale", "kx_set_voice_table", "kx_infer_voices",
-    "kx_infer_packed", "kx_free_packed", "kx_dispatcher_create", "kx_dispatcher_submit", "kx_dispatcher_submit_ex", "kx_dispatcher_model_batches",
+    "kx_infer_packed", "kx_free_packed", "kx_dispatcher_create", "kx_dispatcher_create_warm", "kx_dispatcher_submit", "kx_dispatcher_submit_ex", "kx_dispatcher_model_batches",
     "kx_dispatcher_stats", "kx_dispatcher_failures", "kx_dispatcher_destroy", "kx_debug_tap",
 ]
 
@@ -383,6 +385,16 @@ class HipKoko:
         self._check(self._lib.kx_arena_bytes(self._h, out))
         return list(out)
 
+    def info(self):
+        """kx_model_info as a dict: source variant, whether the arithmetic is the reference's for that file, conv mode, vocabulary,
+        voices, CU partition."""
+        out = (C.c_int64 * 8)()
+        self._check(self._lib.kx_model_info(self._h, out))
+        kinds = {0: "kxw container", 1: "onnx fp32", 2: "onnx fp16/bf16 (widened)", 3: "onnx 8-bit quantised (weights de-quantised)",
+                 4: "onnx 4-bit quantised (weights de-quantised)", -1: "cached conversion", -2: "device blob"}
+        return {"variant": int(out[0]), "variant_name": kinds.get(int(out[0]), "?"), "reference_arithmetic": bool(out[1]), "conv_mode": int(out[2]),
+                "n_vocab": int(out[3]), "n_voices": int(out[4]), "cu_partition": int(out[5]), "cu_partitions": int(out[6]), "cus": int(out[7])}
+
     def status(self):
         """[recurrence in use (0 resident / 1 streaming), hand-off time-outs, clean forwards until the resident forms return, re-run calls]."""
         out = (C.c_int64 * 4)()
@@ -486,12 +498,17 @@ class Dispatcher:
     """Batching front of one or more HipKoko models (one per GPU): the replacement for the reference's
     one-request-at-a-time `Mutex<Session>` (ort_koko.rs:78).  `submit` blocks and is thread-safe."""
 
-    def __init__(self, models: Sequence[HipKoko], max_batch: int = 64, max_wait_us: int = 2000):
+    def __init__(self, models: Sequence[HipKoko], max_batch: int = 64, max_wait_us: int = 2000, warm: Optional[Sequence[int]] = None):
+        """warm = (tokens, frames per token): one discarded forward of max_batch such utterances on every model first
+        (kx_dispatcher_create_warm), so that no request ever pays for an arena growing."""
         self._lib = load_library()
         self._models = list(models)  # keep them alive
         arr = (C.c_void_p * len(self._models))(*[m._h for m in self._models])
         err = C.create_string_buffer(256)
-        self._d = self._lib.kx_dispatcher_create(arr, len(self._models), max_batch, max_wait_us, err, len(err))
+        if warm:
+            self._d = self._lib.kx_dispatcher_create_warm(arr, len(self._models), max_batch, max_wait_us, int(warm[0]), int(warm[1]), err, len(err))
+        else:
+            self._d = self._lib.kx_dispatcher_create(arr, len(self._models), max_batch, max_wait_us, err, len(err))
         if not self._d:
             raise RuntimeError(f"dispatcher: {err.value.decode()}")
 

@@ -593,3 +593,40 @@ def test_chunks_of_a_long_text_batched_equal_chunk_by_chunk(hip_model):
     audio, dur = o.forward(ids, row, 1.0, seed=11, utt=1, f0_override=f0[0], n_override=n_c, har_override=har)
     assert got.shape[0] == 600 * int(dur.sum())
     assert np.abs(got - audio.numpy()).max() < TOL_WAVE
+
+
+def test_kx_init_on_a_real_device():
+    """`init_ort` (kokorox/src/onn/mod.rs:19-49) loads the runtime and reports failure as a string; its counterpart checks that the
+    device exists and is a gfx950: a valid id succeeds, ids outside the visible devices fail with a message, nothing panics."""
+    import ctypes as C
+    from kokorox_amd import hip_koko as hk
+    lib = hk.load_library()
+    err = C.create_string_buffer(256)
+    assert lib.kx_init(0, err, len(err)) == 0, err.value
+    assert lib.kx_init(99, err, len(err)) == 1 and b"device id out of range" in err.value, err.value
+    assert lib.kx_init(-1, err, len(err)) == 1 and b"device id out of range" in err.value, err.value
+    assert lib.kx_init(0, None, 0) == 0  # (no message buffer is fine)
+
+
+def test_dispatcher_warm_up_sizes_the_arenas_before_the_first_request(blob_path):
+    """kx_dispatcher_create_warm: one discarded forward of the largest expected shape per model, so the first real batch finds its
+    arenas (round 4's soak saw a 1.3 s outlier where an arena grew under a request)."""
+    from kokorox_amd import hip_koko as hk
+    from kokorox_amd import weights as W
+    from oracle import kokoro_ref as R
+    m = hk.HipKoko.new(blob_path)
+    try:
+        assert m.arena_bytes() == [0, 0, 0]
+        d = hk.Dispatcher([m], max_batch=8, max_wait_us=500, warm=(64, 6))
+        try:
+            before = m.arena_bytes()
+            assert min(before) > 0
+            ids = R.synthetic_inputs(1, 40, seed=8)[0]
+            style_row = W.synthetic_voices(1)[0, 40, 0]
+            out = d.submit(list(ids), list(style_row), 1.0, seed=2)
+            assert out.shape[0] > 0 and np.isfinite(out).all()
+            assert m.arena_bytes() == before, "an arena grew under the first request"
+        finally:
+            d.close()
+    finally:
+        m.close()

@@ -115,9 +115,15 @@ def test_kx_create_opens_the_onnx_file_itself(blob_path, golden, tmp_path, style
     m = hk.HipKoko.new(src)  # the .onnx path, as koko.rs:570-573 passes it
     try:
         out = m.infer([list(ids)], [list(style_row)], 1.0, seed=6)
+        info = m.info()
     finally:
         m.close()
     np.testing.assert_array_equal(out, ref)
+    # kx_model_info names what was loaded, and says that the quantised variants do NOT run the reference's arithmetic (ORT
+    # quantises the activations at run time; this library de-quantises the weights and runs f32-class)
+    want = {"fp32": (1, True), "int8": (3, False), "q4": (4, False)}[style]
+    assert (info["variant"], info["reference_arithmetic"]) == want, info
+    assert info["n_vocab"] == 178 and info["cu_partitions"] == 1 and info["cus"] == 256, info
     assert not os.path.exists(src + ".kxw"), "no cache file may appear unasked"
     # compiled C++ host on the same .onnx
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -186,3 +192,46 @@ def test_onnx_cache_replicas_and_error_paths(blob_path, tmp_path, monkeypatch):
     monkeypatch.delenv("KOKOROX_KXW_CACHE")
     with pytest.raises(RuntimeError, match="not a readable ONNX model"):
         hk.HipKoko.replicas(src, [0, 0])
+
+
+def test_four_replicas_on_one_gpu_build_fail_and_destroy(blob_path, monkeypatch):
+    """BASELINE configs[3] / [4] without the 8-GPU node: kx_create_replicas with the one device id named four times --
+    four CU-partitioned models from ONE file read, built one host thread each; they give the bits of a whole-device model; they
+    can be destroyed in any order; and when the build of replica 2 fails (injected) nothing is leaked and every handle is NULL.
+    Distinct-device operation (peer copies over xGMI) stays unverified until an N-GPU run exists."""
+    import torch
+    from kokorox_amd import hip_koko as hk
+    from kokorox_amd import weights as W
+    from oracle import kokoro_ref as R
+    ids = R.synthetic_inputs(1, 20, seed=41)[0]
+    style_row = W.synthetic_voices(1)[0, 20, 0]
+    whole = hk.HipKoko.new(blob_path)
+    try:
+        ref = whole.infer([list(ids)], [list(style_row)], 1.0, seed=3)
+        assert whole.info()["cu_partitions"] == 1
+    finally:
+        whole.close()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for order in ((0, 1, 2, 3), (3, 1, 0, 2)):
+        ms = hk.HipKoko.replicas(blob_path, [0, 0, 0, 0])
+        t_read, t_resident, t_built = hk.HipKoko.replicas_times()
+        assert 0 < t_read <= t_resident <= t_built, (t_read, t_resident, t_built)
+        try:
+            infos = [m.info() for m in ms]
+            assert [(i["cu_partition"], i["cu_partitions"], i["cus"]) for i in infos] == [(k, 4, 64) for k in range(4)], infos
+            for m in ms:
+                np.testing.assert_array_equal(m.infer([list(ids)], [list(style_row)], 1.0, seed=3), ref)
+        finally:
+            for k in order:
+                ms[k].close()
+    # a failed build in the middle: RuntimeError, every handle gone, the device memory back
+    monkeypatch.setenv("KX_TEST_HOOKS", "1")
+    monkeypatch.setenv("KX_TEST_FAIL_REPLICA", "2")
+    with pytest.raises(RuntimeError, match="replica 2"):
+        hk.HipKoko.replicas(blob_path, [0, 0, 0, 0])
+    monkeypatch.delenv("KX_TEST_FAIL_REPLICA")
+    monkeypatch.delenv("KX_TEST_HOOKS")
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB of device memory did not come back"
