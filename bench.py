@@ -73,6 +73,9 @@ def dtype_label(conv_mode: int) -> str:
     if conv_mode == 4:
         return ("f16 operands, f32 accumulate (KOKOROX_CONV=f16: one f16 MFMA per product in the decoder / generator convs; "
                 "NARROWER than the reference's fp32 -- not the headline mode)")
+    if conv_mode == 5:
+        return ("bf16 operands, f32 accumulate (KOKOROX_CONV=bf16: one bf16 MFMA per product in the decoder / generator convs; "
+                "NARROWER than the reference's fp32 -- not the headline mode)")
     return "f32"
 
 
@@ -338,6 +341,8 @@ def replicas_main(a):
             for _ in range(a.warmup):
                 m.infer_device(ids.data_ptr(), T, lens, styles.data_ptr(), speeds, audio.data_ptr(), audio_ld, frames.data_ptr(), seed=2)
                 m.sync()
+            if r == 0:
+                m.profile_enable(True)  # (replica 0's per-launch HIP events: the roofline block, as rank 0's in the torchrun form)
             bar.wait()  # start of the timed region
             for _ in range(a.steps):
                 m.infer_device(ids.data_ptr(), T, lens, styles.data_ptr(), speeds, audio.data_ptr(), audio_ld, frames.data_ptr(), seed=2)
@@ -367,6 +372,15 @@ def replicas_main(a):
         assert (frames.cpu().numpy() == F).all()
     finite = all(bool(torch.isfinite(s[3][:, : 600 * F]).all().item()) for s in state)
     audio_s_per_step = N * B * F * 600 / 24000.0
+    # the dominant kernel's roofline from replica 0's own launches (HIP events on its stream), as rank 0 reports it under torchrun
+    m0 = models[0]
+    n_launch, conv_ms, conv_flops = m0.profile_read()
+    det = m0.profile_detail()
+    conv_bytes = float(det[:, 9].sum()) if len(det) else 0.0
+    m0.profile_enable(False)
+    rl = roofline(m0.get_conv_mode() in (1, 4), conv_flops, conv_ms, n_launch, a.steps, wall, B, T, F, conv_bytes)
+    if rl is not None:
+        rl["measured_on"] = f"replica 0 of {N} (device {dev_ids[0]}" + (f", CU partition 0 of {dev_ids.count(dev_ids[0])}" if dev_ids.count(dev_ids[0]) > 1 else "") + ")"
     out = {
         "metric": f"real-time factor (audio-s/wall-s), 24 kHz, batch={B}",
         "value": audio_s_per_step * a.steps / wall, "unit": "x realtime", "n_gpus": N, "steps": a.steps, "warmup": a.warmup,
@@ -379,7 +393,9 @@ def replicas_main(a):
                    "parallelism": f"utterance-sharded x{N}, single process: kx_create_replicas (one file read, peer fan-out), "
                                   f"one host thread per model, device ids {dev_ids}"},
         "utterances_per_s": N * B * a.steps / wall, "audio_s_per_step": audio_s_per_step, "finite": finite,
-        "weight_broadcast_s": t_fan, "roofline": None, "cpu_baseline": None,
+        "weight_broadcast_s": t_fan, "replicas_times_ms": dict(zip(("file_read", "blob_resident_everywhere", "models_built"), hk.HipKoko.replicas_times())),
+        "roofline": rl,
+        "cpu_baseline": None, "cpu_baseline_note": "the CPU restatement is timed at N = 1 only (python bench.py); see BENCH_r*.json",
         "serve": serve_leg(models) if a.serve else None,
     }
     print(json.dumps(out), flush=True)
@@ -504,7 +520,7 @@ def main():
     n_launch, conv_ms, conv_flops = model.profile_read()
     stats_launches, stats_bytes = model.profile_aux()
     conv_mode = model.get_conv_mode()
-    f16x3 = conv_mode in (1, 4)  # both run the f16 matrix pipe (mode 4 = the opt-in reduced precision, labelled as such)
+    f16x3 = conv_mode in (1, 4, 5)  # all run the 16-bit matrix pipe (modes 4 / 5 = the opt-in reduced precision, labelled as such)
     det = model.profile_detail()
     conv_bytes = float(det[:, 9].sum()) if len(det) else 0.0
     if a.detail and rank == 0:
@@ -607,32 +623,40 @@ def main():
     if a.reduced and rank == 0 and world == 1 and conv_mode == 1:
         model.set_pinned_durations([3, 3, 3, 4])
         model.set_utterance_base(rank * B)
-        model.set_conv_mode(4)
-        try:
-            step()
-            model.sync()
-            model.profile_enable(True)
-            t3 = time.perf_counter()
-            for _ in range(a.steps):
+
+        def reduced_run(mode, label):
+            model.set_conv_mode(mode)
+            try:
                 step()
-            fence()
-            w3 = time.perf_counter() - t3
-            n3, ms3, fl3 = model.profile_read()
-            model.profile_enable(False)
+                model.sync()
+                model.profile_enable(True)
+                t3 = time.perf_counter()
+                for _ in range(a.steps):
+                    step()
+                fence()
+                w3 = time.perf_counter() - t3
+                n3, ms3, fl3 = model.profile_read()
+                model.profile_enable(False)
+            finally:
+                model.set_conv_mode(1)
             # (the family mixes launches at one MFMA per product -- the decoder / generator direct-A convs -- with launches
             # at three: `achieved` is algorithmic FLOPs over time, the issue factor is stated, no pipe utilisation is derived)
             ach3 = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
-            reduced = {"mode": "KOKOROX_CONV=f16: one v_mfma_f32_32x32x16_f16 per product in the decoder / generator convs of the "
-                               "direct-A kernel (f16 operands, f32 accumulate); duration head, F0/N predictor, source, STFT f32-class",
-                       "value": audio_s_per_step * a.steps / w3, "unit": "x realtime", "ms_per_step": w3 / a.steps * 1e3,
-                       "roofline": {"bound": "mfma", "achieved": ach3, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": ach3 / PEAK_F16_MFMA_TFLOPS, "mfma_issue_factor": "1 on the direct-A convs, 3 elsewhere",
-                                    "avg_launch_ms": ms3 / max(n3, 1), "launches_per_step": n3 / max(a.steps, 1)},
-                       "note": "secondary figure; waveform error vs the oracle is measured in tests/test_gpu_forward.py "
-                               "(test_reduced_precision_mode_error_is_bounded)"}
-            progress(f"reduced-precision steps: {w3:.3f} s")
-        finally:
-            model.set_conv_mode(1)
+            progress(f"reduced-precision steps ({label}): {w3:.3f} s")
+            return {"value": audio_s_per_step * a.steps / w3, "unit": "x realtime", "ms_per_step": w3 / a.steps * 1e3,
+                    "roofline": {"bound": "mfma", "achieved": ach3, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": ach3 / PEAK_F16_MFMA_TFLOPS, "mfma_issue_factor": "1 on the direct-A convs, 3 elsewhere",
+                                 "avg_launch_ms": ms3 / max(n3, 1), "launches_per_step": n3 / max(a.steps, 1)}}
+
+        reduced = reduced_run(4, "f16")
+        reduced["mode"] = ("KOKOROX_CONV=f16: one v_mfma_f32_32x32x16_f16 per product in the decoder / generator convs of the "
+                           "direct-A kernel (f16 operands, f32 accumulate); duration head, F0/N predictor, source, STFT f32-class")
+        # the dtype BASELINE configs[2] names, on the same switch: one v_mfma_f32_32x32x16_bf16 per product, bf16 weight image
+        bf = reduced_run(5, "bf16")
+        bf["mode"] = "KOKOROX_CONV=bf16: the same with bf16 operands (v_mfma_f32_32x32x16_bf16): 8 significant bits instead of 11"
+        reduced["bf16"] = bf
+        reduced["note"] = ("secondary figures, never `value`: both leave the 1e-4 parity band; the waveform error of each against the "
+                           "oracle is measured and bounded in tests/test_gpu_forward.py (test_reduced_precision_mode_error_is_bounded)")
 
     # ---- BASELINE configs[1]: one 128-phoneme utterance, fp32-class default mode, batch 1: latency of a call ----------
     lat_b1 = None

@@ -194,7 +194,9 @@ int kx_arena_bytes(kx_model* m, int64_t* out3);
  * f16 MFMA per product (weights and activations rounded to f16, f32 accumulation) -- the library's counterpart of the
  * reference's `model_fp16` / quantised variants run at their own precision (kokorox/src/utils/hf_cache.rs:135-144) and
  * of BASELINE configs[2] "bf16"; duration head, F0 / N predictor, harmonic source and STFT pair stay f32-class.  Never
- * the default: the waveform leaves the 1e-4 parity band (measured bound in tests/test_gpu_forward.py). */
+ * the default: the waveform leaves the 1e-4 parity band (measured bound in tests/test_gpu_forward.py).
+ * 5 = the same on bf16 (env KOKOROX_CONV=bf16; v_mfma_f32_32x32x16_bf16, a bf16 weight image built at the first selection):
+ * the dtype BASELINE configs[2] names; 8 significant bits instead of 11, so its error is ~8x that of mode 4 (same test). */
 int kx_set_conv_mode(kx_model* m, int mode);
 int kx_get_conv_mode(kx_model* m);
 

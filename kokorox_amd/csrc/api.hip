@@ -34,7 +34,7 @@ static void check_device(int device_id) {
 
 extern "C" {
 
-const char* kx_version(void) { return "kokorox-hip 0.3 (gfx950; conv modes: f16x3 split MFMA [default], f32 MFMA, f16 reduced precision [opt-in])"; }
+const char* kx_version(void) { return "kokorox-hip 0.3 (gfx950; conv modes: f16x3 split MFMA [default], f32 MFMA, f16 / bf16 reduced precision [opt-in])"; }
 
 int kx_init(int device_id, char* err, size_t err_len) {
     return guarded_free(err, err_len, [&] { check_device(device_id); });
@@ -342,10 +342,9 @@ int kx_arena_bytes(kx_model* m, int64_t* out3) {
 
 int kx_set_conv_mode(kx_model* m, int mode) {
     return guarded(m, [&](Model& M) {
-        KX_REQUIRE(mode == kx::CONV_F32 || mode == kx::CONV_F16X3 || mode == kx::CONV_F16,
-                   "conv mode must be 0 (f32 MFMA), 1 (f16x3 split MFMA) or 4 (f16, reduced precision)");
-        M.sync();
-        M.conv_mode = mode;
+        KX_REQUIRE(mode == kx::CONV_F32 || mode == kx::CONV_F16X3 || mode == kx::CONV_F16 || mode == kx::CONV_BF16,
+                   "conv mode must be 0 (f32 MFMA), 1 (f16x3 split MFMA), 4 (f16, reduced precision) or 5 (bf16, reduced precision)");
+        M.set_conv_mode(mode);
     });
 }
 

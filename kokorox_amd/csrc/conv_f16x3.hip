@@ -656,6 +656,28 @@ __global__ void pack_convT16_kernel(const float* w, _Float16* dst, int Cin, int 
     }
 }
 
+// image layout [..][hi|lo][k-half][BM][8]: blocks of 2 BM 8 halves of hi followed by as many of lo
+__global__ void image_to_bf16_kernel(const _Float16* src, unsigned short* dst, long n_halves, int plane) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n_halves; e += (long)gridDim.x * blockDim.x) {
+        const long blk = e / (2 * plane), in_blk = e - blk * 2 * plane;
+        if (in_blk >= plane) {
+            dst[e] = 0;  // (the lo slots: unused by the bf16 form)
+            continue;
+        }
+        const float v = (float)src[e] + (float)src[e + plane];
+        unsigned u = __float_as_uint(v);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        dst[e] = (unsigned short)(u >> 16);
+    }
+}
+void launch_image_to_bf16(const void* w16, void* dst, size_t n_halves, hipStream_t s) {
+    const int plane = 2 * 128 * 8;  // BM = 128 images only (the direct-A kernels)
+    const int blocks = (int)((n_halves + 255) / 256 < 4096 ? (n_halves + 255) / 256 : 4096);
+    hipLaunchKernelGGL(image_to_bf16_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const _Float16*>(w16), static_cast<unsigned short*>(dst),
+                       (long)n_halves, plane);
+    KX_HIP(hipGetLastError());
+}
+
 void launch_pack_convT16(const float* w, void* dst, int Cin, int Cout, int sd, int BM, float wscale, hipStream_t s) {
     const long total = (long)packed_conv16_halves(sd * Cout, Cin, 2, BM) / 2;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);

@@ -73,8 +73,11 @@ bool conv16_use_da(int BM, int K, int dil, int stride, int merged) {
 // NLD 16-byte loads and NLD 16-byte LDS writes per lane and the transform is gone from this kernel.  For layers whose input
 // window is staged by many row tiles (the 1024-row decoder convs: 8, the polyphase upsamplers: 20 / 6), each of which would
 // otherwise repeat the transform of the same window (profiles/r05_pmc_sq_*.txt: 9 - 14 vector instructions per MFMA there).
-template <int ACT, int KT, int NTT, bool P1, bool W2 = false, bool S16 = false, bool PRE = false>
+// BF (with P1 only): the reduced-precision form on bf16 instead of f16 (KOKOROX_CONV=bf16: the dtype BASELINE configs[2] names):
+// activations rounded to bf16 (round to nearest even) in the staged image, weights from a bf16 image, v_mfma_f32_32x32x16_bf16.
+template <int ACT, int KT, int NTT, bool P1, bool W2 = false, bool S16 = false, bool PRE = false, bool BF = false>
 __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_da_kernel(const ConvArgs a) {
+    static_assert(!BF || P1, "BF: a form of the reduced-precision kernels only");
     static_assert(!PRE || (!P1 && !S16 && ACT == ACT_NONE), "PRE: the activation lives in the image; f16x3 forms on 32x32x16 only");
     static_assert(!W2 || (KT >= 3 && (KT & 1) && NTT == 8), "W2: odd compile-time tap counts on the 256-column tile");
     static_assert(!S16 || (KT >= 3 && (KT & 1) && !P1 && !W2), "S16: odd compile-time tap counts, three MFMAs per product, 4 x 1 waves");
@@ -103,6 +106,28 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    // a pair of transformed values -> the packed operand halves: f16 hi / lo (split_pair), or one bf16 pair (BF: no low part)
+    auto pack_pair = [](float v0, float v1, unsigned& hi_pk, unsigned& lo_pk) __attribute__((always_inline)) {
+        if constexpr (BF) {
+            auto rne = [](float x) __attribute__((always_inline)) {
+                unsigned u = __builtin_bit_cast(unsigned, x);
+                u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (activations are finite)
+                return u >> 16;
+            };
+            hi_pk = rne(v0) | (rne(v1) << 16);
+            lo_pk = 0u;
+        } else {
+            split_pair(v0, v1, hi_pk, lo_pk);
+        }
+    };
+    using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+    // the high-half product of a P1 form: f16 or bf16 operands
+    auto mfma_hi = [](const half8& ah, const half8& bh, const f32x16& c) __attribute__((always_inline)) {
+        if constexpr (BF)
+            return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), c, 0, 0, 0);
+        else
+            return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+    };
     // XCD-aware tile order (as conv1d_f16x3_kernel: workgroups are dealt round-robin over the 8 XCDs by linear block id, and
     // the blocks of one XCD get a contiguous range of tiles so that the window overlap of neighbouring column tiles is an L2
     // hit), extended to the row tiles: the tiles of one utterance are ordered (column tile, row tile) with the ROW tile
@@ -292,7 +317,7 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
                 const float y = in_act<ACT>(__builtin_fmaf(x8[c] - o.m[c], o.s[c], o.h[c]), a.slope, o.al[c], o.ial[c]);  // (explicit fma: see conv_epilogue.h)
                 y2[q] = y * keep;
             }
-            split_pair(y2[0], y2[1], hp[c2], lp[c2]);
+            pack_pair(y2[0], y2[1], hp[c2], lp[c2]);
         }
         Xb[(0 * 2 + g) * XWp + u] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
         if constexpr (!P1) Xb[(1 * 2 + g) * XWp + u] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
@@ -316,7 +341,7 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
                 const float y = in_act<ACT>(__builtin_fmaf(x8[c] - m, sc, sh), a.slope, al, ial);
                 y2[q] = y * keep;
             }
-            split_pair(y2[0], y2[1], hp[c2], lp[c2]);
+            pack_pair(y2[0], y2[1], hp[c2], lp[c2]);
         }
         uint2* Xw2 = reinterpret_cast<uint2*>(Xb);
         Xw2[((0 * 2 + g) * XWp + u) * 2 + jb] = make_uint2(hp[0], hp[1]);
@@ -415,7 +440,7 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
             y_carry = y;
         } else {
             unsigned hp, lp;
-            split_pair(y_carry, y, hp, lp);
+            pack_pair(y_carry, y, hp, lp);
             const int u = lane + blk_col(j);
             unsigned* Xw = reinterpret_cast<unsigned*>(Xb);
             Xw[((0 * 2 + g) * XWp + u) * 4 + c2] = hp;
@@ -891,7 +916,7 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
                     acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fh[e], acc[0][n], 0, 0, 0);
                     acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fl[e], acc[0][n], 0, 0, 0);
                 }
-                acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fh[e], acc[0][n], 0, 0, 0);
+                acc[0][n] = mfma_hi(ah, fh[e], acc[0][n]);
                 // half-units [h0, h1) of the next chunk's transform ride on this tile (in the last chunk they run on
                 // stale registers into the image nobody reads: cheaper than a second version of the loop)
                 constexpr int h0 = i > I0 ? ((i - I0) * HUX) / (TILES - I0) : 0;
@@ -1029,7 +1054,7 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
                 acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fh[e], acc[0][n], 0, 0, 0);
                 acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fl[e], acc[0][n], 0, 0, 0);
             }
-            acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fh[e], acc[0][n], 0, 0, 0);
+            acc[0][n] = mfma_hi(ah, fh[e], acc[0][n]);
             __builtin_amdgcn_sched_barrier(0);
         }
         // (never past the end: the compiler takes the result of such an asm for dead and available at once, and would
@@ -1138,9 +1163,9 @@ constexpr bool DA_S16 = true;
 constexpr bool DA_S16 = false;
 #endif
 
-template <int ACT, int KT, int NTT, bool W2X = DA_W2, bool PREX = false>
+template <int ACT, int KT, int NTT, bool W2X = DA_W2, bool PREX = false, bool BFX = false>
 static void launch_da_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
-    auto kern = conv1d_f16x3_da_kernel<ACT, KT, NTT, DA_P1, W2X, DA_S16, PREX>;
+    auto kern = conv1d_f16x3_da_kernel<ACT, KT, NTT, DA_P1, W2X, DA_S16, PREX, BFX>;
     constexpr int BN = 32 * NTT;
     // two input buffers (48 / 32 KiB), and never less than the statistics scratch of the epilogue (4 waves x 8.25 KiB)
     constexpr size_t lds_x = 16 * (size_t)2 * 4 * (BN + 128), lds_scr = 4 * 32 * 33 * sizeof(float2);
@@ -1228,7 +1253,7 @@ bool conv16_da_w2_has(int act, int K);                                          
 void launch_conv1d_f16x3_da_w2(const ConvArgs& a, int B, int max_cols, hipStream_t s);  // conv_f16x3_da_w2.hip
 void launch_conv1d_f16x3_da_s16(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn);  // conv_f16x3_da_s16.hip
 
-template <int NTT>
+template <int NTT, bool BFX = false>
 static void launch_da_ntt(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
 #ifdef KX_DA_AUDIT  // (tests/test_asm_audit_cpu.py: the early return keeps the build short; every instantiation is still emitted)
     if (a.act == ACT_SNAKE) launch_da_inst<ACT_SNAKE, 11, 8>(a, B, max_cols, s);
@@ -1248,15 +1273,15 @@ static void launch_da_ntt(const ConvArgs& a, int B, int max_cols, hipStream_t s)
     }
 #endif
     if (a.act == ACT_SNAKE) {
-        if (st && w64 && a.K == 11) launch_da_inst<ACT_SNAKE, 11, NTT>(a, B, max_cols, s);
-        else if (st && w64 && a.K == 7) launch_da_inst<ACT_SNAKE, 7, NTT>(a, B, max_cols, s);
-        else if (st && w64 && a.K == 3) launch_da_inst<ACT_SNAKE, 3, NTT>(a, B, max_cols, s);
-        else launch_da_inst<ACT_SNAKE, 0, NTT>(a, B, max_cols, s);
+        if (st && w64 && a.K == 11) launch_da_inst<ACT_SNAKE, 11, NTT, DA_W2, false, BFX>(a, B, max_cols, s);
+        else if (st && w64 && a.K == 7) launch_da_inst<ACT_SNAKE, 7, NTT, DA_W2, false, BFX>(a, B, max_cols, s);
+        else if (st && w64 && a.K == 3) launch_da_inst<ACT_SNAKE, 3, NTT, DA_W2, false, BFX>(a, B, max_cols, s);
+        else launch_da_inst<ACT_SNAKE, 0, NTT, DA_W2, false, BFX>(a, B, max_cols, s);
     } else if (a.act == ACT_LEAKY) {
-        if (st && w64 && a.K == 3) launch_da_inst<ACT_LEAKY, 3, NTT>(a, B, max_cols, s);
-        else launch_da_inst<ACT_LEAKY, 0, NTT>(a, B, max_cols, s);
+        if (st && w64 && a.K == 3) launch_da_inst<ACT_LEAKY, 3, NTT, DA_W2, false, BFX>(a, B, max_cols, s);
+        else launch_da_inst<ACT_LEAKY, 0, NTT, DA_W2, false, BFX>(a, B, max_cols, s);
     } else
-        launch_da_inst<ACT_NONE, 0, NTT>(a, B, max_cols, s);
+        launch_da_inst<ACT_NONE, 0, NTT, DA_W2, false, BFX>(a, B, max_cols, s);
 }
 
 #endif  // KX_DA_W2
@@ -1265,6 +1290,14 @@ static void launch_da_ntt(const ConvArgs& a, int B, int max_cols, hipStream_t s)
 #elif defined(KX_DA_P1)
 // bn: 256 or 128, as launch_conv1d_f16x3_da (which forwards here when a.prec1 is set)
 void launch_conv1d_f16x3_da_p1(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn) {
+    if (a.prec1 == 2) {  // bf16 operands: the bf16 form of the weight image
+        KX_REQUIRE(a.w16b != nullptr, "conv1d f16x3 da p1: no bf16 weight image");
+        ConvArgs b16 = a;
+        b16.w16 = a.w16b;
+        if (bn == 256) launch_da_ntt<8, true>(b16, B, max_cols, s);
+        else launch_da_ntt<4, true>(b16, B, max_cols, s);
+        return;
+    }
     if (bn == 256)
         launch_da_ntt<8>(a, B, max_cols, s);
     else

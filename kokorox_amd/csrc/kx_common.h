@@ -103,6 +103,7 @@ struct ConvArgs {
     int up_s, up_pad, up_off, up_reflect, up_cout;
     // f16x3 path (conv_f16x3.hip): split-f16 weight image, 16-channel chunks, 2^-ws to undo the weight scale
     const void* w16;
+    const void* w16b;  // the bf16 form of the same image (prec1 == 2 launches of the direct-A kernel swap it in), or null
     int n_chunks16;
     float w_unscale;
     float x_prescale;  // f16x3: power of two applied to the transformed input before the hi/lo split (w_unscale carries
@@ -116,7 +117,8 @@ struct ConvArgs {
     int xcd_swizzle;               // one-role f16x3 kernel: contiguous column tiles per XCD (1 unless KX_XCD_SWIZZLE=0)
     int ws_force;                  // test hook: 1 = the LDS-DMA kernel forms only (no direct-A kernel), 2 = the direct-A kernel whatever the grid
     unsigned long long* stamps;  // diagnostic build only: per-workgroup {t0,t1,t2,t3,hw_id,xcc_id,0,0}
-    int prec1;  // direct-A conv: the reduced-precision form (one f16 MFMA per product; KOKOROX_CONV=f16, opt-in)
+    int prec1;  // direct-A conv: the reduced-precision forms, opt-in: 1 = one f16 MFMA per product (KOKOROX_CONV=f16), 2 = one bf16
+                // MFMA per product on a bf16 weight image (KOKOROX_CONV=bf16)
     int dephase_cycles, dephase_mode;  // direct-A conv: start delay of half of the first round of workgroups (0 = off)
     int dbg;  // timing ablations (env KX_DBG): 1 skip input staging, 2 skip weight copies, 4 skip MFMA, 8 skip epilogue
     // Flat tile list of a ragged batch (direct-A kernels): tile_prefix[b] = column tiles of the utterances before b (so
@@ -171,7 +173,7 @@ void launch_pack_convT(const float* w, float* dst, int Cin, int Cout, int s, int
 size_t packed_conv_floats(int rows, int Cin, int K, int BM);
 
 // f16x3 split path
-enum ConvMode { CONV_F32 = 0, CONV_F16X3 = 1, CONV_F16X3_LDS = 2, CONV_F16X3_DA = 3, CONV_F16 = 4 };  // (2, 3: test hook only: f16x3 kept on the LDS-DMA kernel forms of conv_f16x3.hip / forced through conv_f16x3_da.hip)
+enum ConvMode { CONV_F32 = 0, CONV_F16X3 = 1, CONV_F16X3_LDS = 2, CONV_F16X3_DA = 3, CONV_F16 = 4, CONV_BF16 = 5 };  // (2, 3: test hook only: f16x3 kept on the LDS-DMA kernel forms of conv_f16x3.hip / forced through conv_f16x3_da.hip)
 void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStream_t s);
 // (act / n_chunks16 / prec1: given, the shapes of the direct-A S16 form get its tiles: 192 or 128 columns, 64-column statistics slots)
 void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int stride, int* bn, int* wn,
@@ -193,6 +195,8 @@ float device_absmax(const float* p, long n, hipStream_t s);
 int pick_weight_shift(float absmax);
 void launch_pack_conv16(const PackSrc& src, void* dst, int Cout, int Cin, int K, int BM, float wscale, hipStream_t s);
 void launch_pack_convT16(const float* w, void* dst, int Cin, int Cout, int sd, int BM, float wscale, hipStream_t s);
+// a split-f16 weight image (hi + lo = the f32 weight to 22 bits) -> the same layout with bf16(hi + lo) in the hi slots (CONV_BF16)
+void launch_image_to_bf16(const void* w16, void* dst, size_t n_halves, hipStream_t s);
 
 // ---- everything else (kernels_misc.hip) ----------------------------------------------
 void launch_vec_add(const float* a, const float* b, float* out, int n, hipStream_t s);

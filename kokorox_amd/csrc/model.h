@@ -22,6 +22,7 @@ struct ConvW {
     int rows = 0, Cin = 0, K = 0, BM = 0, n_chunks = 0;
     int up_s = 0, up_cout = 0;  // polyphase transposed conv
     const void* w16 = nullptr;  // split-f16 image (conv_f16x3.hip)
+    const void* w16b = nullptr; // bf16 form of it (built when KOKOROX_CONV=bf16 / kx_set_conv_mode(5) is first selected)
     int n_chunks16 = 0;
     float unscale = 1.f;        // 2^-ws
     std::string name;           // registry key (diagnostics, kx_set_act_prescale)
@@ -175,6 +176,7 @@ class Model {
     std::mutex mu;
     uint64_t utt_base = 0;
     void set_lanes(int n) { lanes_cfg_ = n < 0 ? 0 : (n > N_LANES ? N_LANES : n); }
+    void set_conv_mode(int mode);  // (mode 5 builds the bf16 weight images on first use)
     int conv_mode = CONV_F16X3;
     int stft_variant = STFT_ONNX;  // the ONNX export's conv-based STFT pair (what the reference runs)
     int device;

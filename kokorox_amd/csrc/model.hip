@@ -30,7 +30,7 @@ struct CuScope {
 
 Model::Model(int dev, int part, int n_parts) : device(dev), part_(part), n_parts_(n_parts) {
     if (const char* e = getenv("KOKOROX_CONV"))
-        conv_mode = (strcmp(e, "f32") == 0) ? CONV_F32 : (strcmp(e, "f16") == 0 ? CONV_F16 : CONV_F16X3);
+        conv_mode = (strcmp(e, "f32") == 0) ? CONV_F32 : (strcmp(e, "f16") == 0 ? CONV_F16 : (strcmp(e, "bf16") == 0 ? CONV_BF16 : CONV_F16X3));
     if (const char* e = getenv("KOKOROX_STFT")) stft_variant = (strcmp(e, "torch") == 0) ? STFT_TORCH : STFT_ONNX;
     // (per-device state of the library -- the per-device turn of the forwards, dynamic-LDS attribute limits, CU counts -- is
     // kept in tables of KX_MAX_DEVICES entries: an id beyond them is refused here, never aliased onto another device's entry)
@@ -483,6 +483,7 @@ void Model::build() {
     convs_[G + "conv_post"] = make_conv(G + "conv_post");
 
     for (auto& kv : convs_) kv.second.name = kv.first;
+    if (conv_mode == CONV_BF16) set_conv_mode(CONV_BF16);  // (KOKOROX_CONV=bf16: the images exist from the start)
     for (auto& kv : lstms_) kv.second.ih.name = kv.first + ".ih";
     KX_HIP(hipMalloc((void**)&fc_dev_, fc_host_.size() * sizeof(FcDesc)));
     owned_.push_back(fc_dev_);
@@ -610,12 +611,13 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     a.up_off = o.up_off;
     a.up_reflect = o.up_reflect;
     a.up_cout = w.up_cout ? w.up_cout : 1;
-    const bool f16 = conv_mode == CONV_F16X3 || conv_mode == CONV_F16;
+    const bool f16 = conv_mode == CONV_F16X3 || conv_mode == CONV_F16 || conv_mode == CONV_BF16;
     // reduced-precision mode (opt-in): the decoder and generator convs that take the direct-A kernel run one f16 MFMA
     // per product; everything upstream of the F0 / N curves (duration head, prosody predictor) and every kernel that is
     // not the direct-A conv (harmonic source, STFT pair, k = 1 GEMMs, conv_post) stays f32-class (hard part 3)
-    a.prec1 = (conv_mode == CONV_F16 && p1_region_) ? 1 : 0;
+    a.prec1 = (conv_mode == CONV_F16 && p1_region_) ? 1 : ((conv_mode == CONV_BF16 && p1_region_ && w.w16b) ? 2 : 0);
     a.w16 = w.w16;
+    a.w16b = w.w16b;
     a.n_chunks16 = w.n_chunks16;
     static const int xcd_swz = getenv("KX_XCD_SWIZZLE") ? atoi(getenv("KX_XCD_SWIZZLE")) : 1;
     a.xcd_swizzle = xcd_swz;
@@ -633,7 +635,7 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
         int bn, wn;
         if (f16) {
             conv16_pick_tile(w.BM, max_c, B_, w.rows, w.K, o.dil, o.stride, &bn, &wn, 0, true, o.act, w.n_chunks16,
-                             conv_mode == CONV_F16 && p1_region_);
+                             (conv_mode == CONV_F16 || conv_mode == CONV_BF16) && p1_region_);
         } else {
             bn = conv_bn(w.BM);
             wn = w.BM == 128 ? 2 : 4;
@@ -963,6 +965,26 @@ void Model::check_dev_err() {
     throw LstmTimeout("device error word " + std::to_string(e) +
                       ": a part of the resident-weights LSTM recurrence never saw its partner; this call's result is invalid; the "
                       "model runs the streaming recurrence (same bits) for the next " + std::to_string(LSTM_REARM_AFTER) + " forwards");
+}
+
+void Model::set_conv_mode(int mode) {
+    sync();
+    if (mode == CONV_BF16) {
+        // bf16 forms of the direct-A kernels' weight images, once: bf16(hi + lo) from the split-f16 image (160 MB more)
+        KX_HIP(hipSetDevice(device));
+        for (auto& kv : convs_) {
+            ConvW& c = kv.second;
+            if (c.w16b || !c.w16 || c.BM != 128) continue;
+            const size_t nh = packed_conv16_halves(c.rows, c.Cin, c.K, c.BM);
+            void* p = nullptr;
+            KX_HIP(hipMalloc(&p, nh * 2));
+            owned_.push_back(p);
+            launch_image_to_bf16(c.w16, p, nh, stream_);
+            c.w16b = p;
+        }
+        KX_HIP(hipStreamSynchronize(stream_));
+    }
+    conv_mode = mode;
 }
 
 void Model::info(int64_t out[8]) const {
@@ -1889,8 +1911,11 @@ void host_out_share(void* base, void* const* parts, int n) {
     if (!base || n <= 0) return;
     HostPool& P = host_pool();
     std::lock_guard<std::mutex> lk(P.mu);
-    P.refs[base] = n;
-    for (int i = 0; i < n; ++i) P.alias[parts[i]] = base;
+    // one reference per DISTINCT pointer: two parts with the same address (a zero-byte part; cannot happen today, an utterance
+    // has at least one frame) would share one key, and a count of n would then never come down to zero
+    int distinct = 0;
+    for (int i = 0; i < n; ++i) distinct += P.alias.emplace(parts[i], base).second ? 1 : 0;
+    P.refs[base] = distinct;
 }
 
 void host_out_free(void* p) {

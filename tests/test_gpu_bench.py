@@ -73,4 +73,14 @@ def test_bench_blocks_and_single_process_replicas():
     d = _last_json(r.stdout)
     assert REQUIRED <= set(d)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["weight_broadcast_s"] > 0
+    # the single-process N-GPU line carries replica 0's roofline (HIP events on its own stream) and says where the CPU baseline is
+    rl = d["roofline"]
+    assert rl["bound"] == "mfma" and 0 < rl["frac"] < 1 and rl["achieved"] > 0 and "replica 0 of 2" in rl["measured_on"]
+    assert d["cpu_baseline"] is None and "N = 1" in d["cpu_baseline_note"]
+    assert d["replicas_times_ms"]["models_built"] >= d["replicas_times_ms"]["file_read"] > 0
+    lb = _last_json(subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--batch", "4", "--cpu-utts", "0", "--pcie", "0",
+                                    "--serve", "0", "--free-run", "0", "--reduced", "0", "--latency-b1", "10"], cwd=ROOT, capture_output=True,
+                                   text=True, timeout=600).stdout)["latency_b1"]
+    hm = lb["host_ms"]  # (kx_call_times: where a batch-1 call's wall time goes on the host)
+    assert 0 < hm["front_queued"] <= hm["front_done"] <= hm["back_planned"] <= hm["back_queued"] <= lb["median_ms"]
     assert abs(d["audio_s_per_step"] - 2 * 4 * 10.55) < 1e-6 and "kx_create_replicas" in d["config"]["parallelism"]

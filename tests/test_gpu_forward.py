@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 
 TOL_WAVE = 1e-4
 REDUCED_TOL = 2e-3  # opt-in f16 mode: bound on max|d| / max(1, max|waveform|), measured (profiles/r03_reduced_precision.txt)
+REDUCED_TOL_BF16 = 1.6e-2  # opt-in bf16 mode: 8 significant bits instead of 11
 FRONT = ["bert.emb", "bert.layer0", "bert.out", "d_en", "dur_enc.0", "dur_enc.1", "dur_enc.2", "dur.lstm",
          "pred.shared", "pred.N", "text_enc.cnn", "text_enc.out", "dec.encode", "dec.decode.0", "dec.decode.1",
          "dec.decode.2", "dec.decode.3"]
@@ -208,19 +209,21 @@ def test_lstm_handoff_timeout_is_survived_without_changing_a_bit(blob_path):
         m.close()
 
 
-def test_reduced_precision_mode_error_is_bounded(hip_model, oracle):
-    """The opt-in reduced-precision mode (kx_set_conv_mode(4) / KOKOROX_CONV=f16: one f16 MFMA per product in the decoder
-    and generator convs; the reference's counterpart are its model_fp16 / quantised variants, hf_cache.rs:135-144).  It is
-    NOT inside the 1e-4 parity band and never the default; what it must keep: durations and the F0 / N curves exactly as in
-    the default mode (the front half stays f32-class), and a waveform within the bound measured on this workload
-    (profiles/r03_reduced_precision.txt), under the usual protocol."""
+@pytest.mark.parametrize("mode,name,tol", [(4, "f16", REDUCED_TOL), (5, "bf16", REDUCED_TOL_BF16)])
+def test_reduced_precision_mode_error_is_bounded(hip_model, oracle, mode, name, tol):
+    """The opt-in reduced-precision modes (kx_set_conv_mode(4) / KOKOROX_CONV=f16 and, round 5, kx_set_conv_mode(5) /
+    KOKOROX_CONV=bf16 -- the dtype BASELINE configs[2] names: one 16-bit MFMA per product in the decoder and generator convs; the
+    reference's counterpart are its model_fp16 / quantised variants, hf_cache.rs:135-144).  They are NOT inside the 1e-4 parity
+    band and never the default; what they must keep: durations and the F0 / N curves exactly as in the default mode (the front
+    half stays f32-class), and a waveform within the bound measured on this workload (profiles/r03_reduced_precision.txt for
+    f16; bf16 carries 8 significant bits instead of 11: 8x the bound), under the usual protocol."""
     from kokorox_amd import hip_koko as hk
     ids, styles = _inputs([24], seed0=500)
     base = hip_model.infer([list(ids[0])], [list(styles[0])], 1.0, seed=2, flags=hk.KX_FLAG_TAPS)
     f0_base = hip_model.tap("pred.F0", 0)
-    hip_model.set_conv_mode(4)
+    hip_model.set_conv_mode(mode)
     try:
-        assert hip_model.get_conv_mode() == 4
+        assert hip_model.get_conv_mode() == mode
         out = hip_model.infer([list(ids[0])], [list(styles[0])], 1.0, seed=2, flags=hk.KX_FLAG_TAPS)
         f0, n_c, har = hip_model.tap("pred.F0", 0), hip_model.tap("pred.N", 0)[0], hip_model.tap("gen.har", 0)
         np.testing.assert_array_equal(f0, f0_base)  # nothing upstream of the curves is reduced
@@ -228,7 +231,10 @@ def test_reduced_precision_mode_error_is_bounded(hip_model, oracle):
         audio, dur = oracle.forward(ids[0], styles[0], 1.0, seed=2, utt=0, f0_override=f0[0], n_override=n_c, har_override=har)
         err = float(np.abs(out - audio.numpy()).max())
         scale = float(np.abs(audio.numpy()).max())
-        assert 1e-6 < err < REDUCED_TOL * max(scale, 1.0), (err, scale)  # really reduced, and bounded
+        print(f"reduced precision {name}: max|d| vs the oracle {err:.3e} (waveform scale {scale:.3f})")
+        assert 1e-6 < err < tol * max(scale, 1.0), (err, scale)  # really reduced, and bounded
+        if mode == 5:
+            assert err > 2e-4, err  # (coarser than f16's measured 3 - 3.5e-4 would be expected; far outside the 1e-4 band in any case)
     finally:
         hip_model.set_conv_mode(1)
     again = hip_model.infer([list(ids[0])], [list(styles[0])], 1.0, seed=2)
