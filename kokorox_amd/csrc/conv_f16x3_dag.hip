@@ -294,12 +294,22 @@ __global__ __launch_bounds__(256, 3) void conv1d_f16x3_dagn_kernel(const ConvArg
     const float keep = pok ? a.x_prescale : 0.f;
     const int cmax_in = a.Cin - 1;
     // byte offsets of the lane's eight values from the first row of a chunk (checked < 2^31 at launch): a chunk's loads take a
-    // scalar base and these, no address arithmetic.  (Cin is a multiple of 16 here -- checked at launch -- so a chunk has no
-    // missing channels; the up to two chunks past the end that complete the last round of three re-read the last chunk and
-    // are multiplied by zero.)
-    unsigned voff[8];
+    // scalar base and these, no address arithmetic.  The chunks past the end that complete the last round of the ring re-read
+    // the last chunk and are multiplied by zero.  A PARTIAL last chunk (Cin not a multiple of 16: the 1090- and 514-channel
+    // shortcuts of the decoder; round 5) reads its missing channels from the last real one (an offset set of its own, chosen by
+    // the wave-uniform chunk index) and multiplies them by zero.
+    unsigned voff[8], voff_last[8];
+    unsigned last_ok = 0;  // bit j: channel j of the lane's octet exists in the last chunk
+    const int c_last = n_chunks - 1;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) voff[j] = (unsigned)(((long)(h * 8 + j) * a.x_ld + xoff) * 4);
+    for (int j = 0; j < 8; ++j) {
+        voff[j] = (unsigned)(((long)(h * 8 + j) * a.x_ld + xoff) * 4);
+        const int ci = c_last * CK16 + h * 8 + j;
+        const int cl = ci <= cmax_in ? ci : cmax_in;
+        last_ok |= ci <= cmax_in ? (1u << j) : 0u;
+        voff_last[j] = (unsigned)(((long)(cl - c_last * CK16) * a.x_ld + xoff) * 4);
+    }
+    const bool partial = (a.Cin % CK16) != 0;
     const uint4* wlane = reinterpret_cast<const uint4*>(a.w16) + (long)ct * n_chunks * tap_units + h * BM + wave * 32 + r;
     using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
     u32x4 ahs[R], als[R];
@@ -311,8 +321,12 @@ __global__ __launch_bounds__(256, 3) void conv1d_f16x3_dagn_kernel(const ConvArg
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a_hi) : "v"(p) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a_lo) : "v"(p + 2 * BM) : "memory");
         const float* base = a.x + (long)cc * CK16 * a.x_ld;
+        const bool lastp = partial && cc == c_last;  // (wave-uniform)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) asm volatile("global_load_dword %0, %1, %2" : "=v"(rw[j]) : "v"(voff[j]), "s"(base) : "memory");
+        for (int j = 0; j < 8; ++j) {
+            const unsigned vo = lastp ? voff_last[j] : voff[j];
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(rw[j]) : "v"(vo), "s"(base) : "memory");
+        }
     };
     // (the wait has no operands, a scheduling barrier follows, and only then are the registers handed on: conv_f16x3_da.hip)
     auto wait_chunk = [&](const bool first, u32x4& a_hi, u32x4& a_lo, float (&rw)[8]) __attribute__((always_inline)) {
@@ -327,10 +341,11 @@ __global__ __launch_bounds__(256, 3) void conv1d_f16x3_dagn_kernel(const ConvArg
     auto split8 = [&](int c, const float (&rw)[8], half8& bh, half8& bl) __attribute__((always_inline)) {
         unsigned hp[4], lp[4];
         const float kc = keep * (c < n_chunks ? 1.f : 0.f);
+        const unsigned okm = (partial && c >= c_last) ? last_ok : 0xffu;  // (chunks past the end are zeroed by kc already)
 #pragma unroll
         for (int c2 = 0; c2 < 4; ++c2) {
-            const float y0 = in_act<ACT>(rw[2 * c2], a.slope, 1.f, 1.f) * kc;
-            const float y1 = in_act<ACT>(rw[2 * c2 + 1], a.slope, 1.f, 1.f) * kc;
+            const float y0 = in_act<ACT>(rw[2 * c2], a.slope, 1.f, 1.f) * (((okm >> (2 * c2)) & 1u) ? kc : 0.f);
+            const float y1 = in_act<ACT>(rw[2 * c2 + 1], a.slope, 1.f, 1.f) * (((okm >> (2 * c2 + 1)) & 1u) ? kc : 0.f);
             split_pair(y0, y1, hp[c2], lp[c2]);
         }
         bh = __builtin_bit_cast(half8, make_uint4(hp[0], hp[1], hp[2], hp[3]));
@@ -406,9 +421,9 @@ void launch_conv1d_f16x3_dag(const ConvArgs& a, int B, int max_cols, hipStream_t
     // 768-row GEMMs at batch 64 alone it is twice as slow as the 128 x 128 form: 3.09 against 1.59 ms for 12 launches).
     static const int narrow = getenv("KX_DAGN") ? atoi(getenv("KX_DAGN")) : 1;
     const long wgs = (long)((max_cols + 127) / 128) * ((a.Cout + 127) / 128) * (a.merge_T > 0 ? 1 : B);
-    // (the narrow form: whole chunks only, and 32-bit byte offsets into the input)
+    // (the narrow form: 32-bit byte offsets into the input)
     const long x_span = ((long)a.x_bs * (a.merge_T > 0 ? a.merge_B : B) + (long)CK16 * a.x_ld) * 4;
-    const bool narrow_ok = a.Cin % CK16 == 0 && x_span < (1L << 31);
+    const bool narrow_ok = x_span < (1L << 31);
     if (narrow_ok && (narrow == 2 || (narrow && 2 * wgs <= conv16_cu_count()))) {
         if (a.act == ACT_LEAKY)
             launch_dagn_inst<ACT_LEAKY>(a, B, max_cols, s);

@@ -23,7 +23,10 @@ static int pre_env_int(const char* name, int dflt) {
 // Which layers get a pre-split image: by the layer's shape alone (never by the batch, so an utterance's bits do not depend on
 // what it is batched with -- and the arithmetic is the same either way).  KX_PRE_ROWS: smallest row count (0 = never).
 bool conv16_pre_shape(int BM, int rows, int K, int dil, int stride, int act, int in_up2) {
-    static const int min_rows = pre_env_int("KX_PRE_ROWS", 768);  // >= 6 row tiles per window
+    // >= 4 row tiles per window.  At batch 64 the 512-row layers (the predictor's F0 / N convs, decode.3) gain from it what their six
+    // extra passes cost (profiles/r05_experiments_not_kept.txt: 113.32 vs 113.28 ms); at batch 1 they then take the narrow form
+    // (conv_f16x3_dapn.hip: 64 workgroups instead of 16 on the forward's critical path), which is what the rule is set by.
+    static const int min_rows = pre_env_int("KX_PRE_ROWS", 512);
     return min_rows > 0 && BM == 128 && rows >= min_rows && stride == 1 && K >= 2 && !in_up2 && act != ACT_SNAKE &&
            conv16_da_eligible(BM, K, dil, stride, 0) && conv16_use_da(BM, K, dil, stride, 0);
 }

@@ -51,12 +51,14 @@ def shape_groups(detail_path):
 
 def kernel_group(name):
     import re
-    m = re.search(r"da_kernel<(\d+), (\d+), (\d+)", name)
+    m = re.search(r"da_kernel<(\d+), (\d+), (\d+)((?:, (?:true|false))*)>", name)
     if m:
         act, kt = int(m.group(1)), int(m.group(2))
+        flags = [v.strip() == "true" for v in m.group(4).split(",")[1:]]  # P1, W2, S16, PRE, BF
+        pre = len(flags) >= 4 and flags[3]
         if act == 2 and kt in (3, 7, 11):
             return f"da<2, {kt}, *> snake resblock convs, {kt} taps"
-        if act == 1 and kt == 0:
+        if (act == 1 and kt == 0) or (pre and kt == 0):  # (round 5: the pre-split form of the run-time-tap kernel runs the polyphase convs only)
             return "da<1, 0, 8> polyphase transposed convs"
         if kt == 0:
             return "dag / da<0, 0, 8> k = 1"
@@ -116,6 +118,12 @@ def main(fetch_dir, write_dir, out, bench_stdout, family="conv1d_f16x3_kernel<12
         res["per_instantiation_note"] = ("traffic summed over every launch of the run; algorithmic bytes = bench.py --detail of the same "
                                          "workload, summed over the shapes each instantiation runs (k = 1 shapes that the LDS-DMA "
                                          "statistics form runs are counted under 'dag / da<0, 0, 8> k = 1')")
+    sp = [k for k in f if "split_image_kernel" in k]
+    if sp:  # the pre-split passes (conv_f16x3_pre.hip): outside the family, reported beside it
+        res["split_image_passes"] = {"launches": sum(f[k][0] for k in sp), "fetch_bytes": sum(f[k][1] for k in sp) * 1024 * FETCH_FACTOR,
+                                     "write_bytes": sum(w[k][1] for k in sp if k in w) * 1024,
+                                     "note": "one elementwise pass per pre-split input image (1024-row decoder convs, polyphase upsamplers): "
+                                             "reads the f32 tensor once, writes the hi / lo image once; not counted in the family's traffic"}
     res["workload"] = {"batch": bench["config"]["batch_per_gpu"], "tokens": bench["config"]["tokens"],
                        "frames": bench["config"]["frames"], "conv_mode": mode}
     json.dump(res, open(out, "w"), indent=1)
