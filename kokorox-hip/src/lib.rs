@@ -184,6 +184,49 @@ impl HipKoko {
         Ok(hs.into_iter().map(|h| HipKoko { h }).collect())
     }
 
+    /// A model confined to CUs `[part, part + 1) x CUs / n_parts` of the device: partitions run their forwards side by side on one
+    /// GPU without competing for a CU (`kx_create_replicas` does this for a device id that is named several times).
+    pub fn partition(model_path: String, device_id: i32, part: i32, n_parts: i32) -> Result<Self, String> {
+        let p = CString::new(model_path).map_err(|e| e.to_string())?;
+        let mut err = vec![0 as c_char; 512];
+        let h = unsafe { kx_create_partition(p.as_ptr(), device_id, part, n_parts, err.as_mut_ptr(), err.len()) };
+        if h.is_null() {
+            return Err(cstr_buf(&err));
+        }
+        Ok(HipKoko { h })
+    }
+
+    /// Milestones of the process's last `replicas` call in ms from its entry: file read (+ conversion), blob resident on every
+    /// device, every model built.
+    pub fn replicas_times() -> [f64; 3] {
+        let mut t = [0f64; 3];
+        unsafe { kx_replicas_times(t.as_mut_ptr()) };
+        t
+    }
+
+    /// `[weight-file variant, reference arithmetic (0 for the de-quantised int8 / q4 variants), conv mode, vocabulary rows,
+    /// voices, CU partition, partitions, CUs]` (kx_model_info).
+    pub fn info(&self) -> Result<[i64; 8], Box<dyn Error>> {
+        let mut o = [0i64; 8];
+        self.check(unsafe { kx_model_info(self.h, o.as_mut_ptr()) })?;
+        Ok(o)
+    }
+
+    /// `[recurrence form (0 resident weights / 1 streaming fall-back), hand-off time-outs, clean forwards until the resident forms
+    /// return, transparently re-run calls]`: all zero in a healthy deployment (kx_model_status).
+    pub fn status(&self) -> Result<[i64; 4], Box<dyn Error>> {
+        let mut o = [0i64; 4];
+        self.check(unsafe { kx_model_status(self.h, o.as_mut_ptr()) })?;
+        Ok(o)
+    }
+
+    /// Host-side milestones of the last call in ms from its entry (kx_call_times).
+    pub fn call_times(&self) -> Result<[f64; 4], Box<dyn Error>> {
+        let mut o = [0f64; 4];
+        self.check(unsafe { kx_call_times(self.h, o.as_mut_ptr()) })?;
+        Ok(o)
+    }
+
     /// A model from a weight blob that already sits in this GPU's memory (after an RCCL broadcast).
     ///
     /// # Safety
@@ -449,6 +492,31 @@ impl HipKokoDispatcher {
             return Err(cstr_buf(&err));
         }
         Ok(HipKokoDispatcher { d, _models: models })
+    }
+
+    /// `new`, after one discarded forward of `max_batch` utterances x `warm_tokens` tokens at `warm_frames_per_token` frames per
+    /// token on every model: what a server should call, so that no request ever pays for an arena growing.
+    pub fn new_warm(models: Vec<HipKoko>, max_batch: i32, max_wait_us: i32, warm_tokens: i32, warm_frames_per_token: i32) -> Result<Self, String> {
+        let mut hs: Vec<*mut KxModel> = models.iter().map(|m| m.h).collect();
+        let mut err = vec![0 as c_char; 256];
+        let d = unsafe {
+            kx_dispatcher_create_warm(hs.as_mut_ptr(), hs.len() as c_int, max_batch, max_wait_us, warm_tokens, warm_frames_per_token,
+                                      err.as_mut_ptr(), err.len())
+        };
+        if d.is_null() {
+            return Err(cstr_buf(&err));
+        }
+        Ok(HipKokoDispatcher { d, _models: models })
+    }
+
+    /// Per-model health (true = takes work; false = failed a batch with a device error twice in a row and is out), the number of
+    /// models marked failed and of requests that went back to the queue for another model.
+    pub fn health(&self) -> (Vec<bool>, i64, i64) {
+        let n = self._models.len();
+        let mut h = vec![0i32; n];
+        let (mut f, mut r) = (0i64, 0i64);
+        unsafe { kx_dispatcher_health(self.d, h.as_mut_ptr(), n as c_int, &mut f, &mut r) };
+        (h.into_iter().map(|v| v != 0).collect(), f, r)
     }
 
     /// One utterance: `ids` already wrapped with the two 0 pads (koko.rs:1169-1173), `style` = 256 floats.
