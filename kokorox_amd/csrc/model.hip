@@ -81,14 +81,29 @@ void Model::new_stream(hipStream_t* s) {
 }
 
 Model::~Model() {
+    const bool tr = getenv("KX_TRACE_DTOR") != nullptr;
+    // CU-masked streams: with the ROCm 7.2 runtime of this image (not with the one torch bundles) hipStreamDestroy of the SECOND
+    // masked stream of a device hung for good although every stream had been synchronised on its own; behind one
+    // hipDeviceSynchronize it returns at once (probed: tools/_dbg in git history, profiles/r05_experiments_not_kept.txt item 9).
+    // KX_MASKED_DESTROY=0 leaves the masked streams to the runtime's own teardown instead (also probed: clean exit).
+    const int md = getenv("KX_MASKED_DESTROY") ? atoi(getenv("KX_MASKED_DESTROY")) : 2;
+    const bool masked = !cu_mask_.empty();
+    if (masked && md == 2) (void)hipDeviceSynchronize();
+    auto destroy = [&](hipStream_t st) { if (!masked || md >= 1) (void)hipStreamDestroy(st); };
+    auto T = [&](const char* what) { if (tr) { fprintf(stderr, "dtor: %s\n", what); fflush(stderr); } };
     (void)hipSetDevice(device);
+    T("sync main");
     if (stream_) (void)hipStreamSynchronize(stream_);
+    T("sync side");
     if (stream2_) (void)hipStreamSynchronize(stream2_);
     for (int i = 1; i < N_LANES; ++i)
         if (lanes_[i].stream) {
+            T("sync lane");
             (void)hipStreamSynchronize(lanes_[i].stream);
-            (void)hipStreamDestroy(lanes_[i].stream);
+            T("destroy lane");
+            destroy(lanes_[i].stream);
         }
+    T("lanes gone");
     for (hipEvent_t e : lane_ev_) (void)hipEventDestroy(e);
     for (void* p : owned_) (void)hipFree(p);
     if (d_dev_err_) (void)hipFree(d_dev_err_);
@@ -104,8 +119,11 @@ Model::~Model() {
     for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
-    if (stream2_) (void)hipStreamDestroy(stream2_);
-    if (stream_) (void)hipStreamDestroy(stream_);
+    T("destroy side");
+    if (stream2_) destroy(stream2_);
+    T("destroy main");
+    if (stream_) destroy(stream_);
+    T("done");
 }
 
 // ---- weight container ------------------------------------------------------------------------

@@ -20,7 +20,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 # every translation unit this file audits, with its extra flags: compiled to assembly side by side on first use (five hipcc runs
 # of 10 - 70 s each; in a row they were most of the CPU suite's time)
 _UNITS = {"conv_f16x3_da.hip": ("-DKX_DA_AUDIT",), "conv_f16x3_da_p1.hip": ("-DKX_DA_AUDIT",), "conv_f16x3_da_w2.hip": ("-DKX_DA_AUDIT",),
-          "conv_f16x3_da_s16.hip": ("-DKX_DA_AUDIT",), "conv_f16x3_dag.hip": ()}
+          "conv_f16x3_da_s16.hip": ("-DKX_DA_AUDIT",), "conv_f16x3_dag.hip": (), "conv_f16x3_da_pre.hip": (), "conv_f16x3_dapn.hip": ()}
 _ASM_JOBS = {}
 
 
@@ -38,7 +38,7 @@ def _asm(src, tmp_path, *flags):
         import tempfile
         from concurrent.futures import ThreadPoolExecutor
         out_dir = tempfile.mkdtemp(prefix="kx_asm_audit_")
-        ex = ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1))
+        ex = ThreadPoolExecutor(max_workers=min(7, os.cpu_count() or 1))
         for u, fl in _UNITS.items():
             _ASM_JOBS[u] = ex.submit(_asm_one, u, fl, out_dir)
         ex.shutdown(wait=False)
@@ -185,3 +185,49 @@ def test_direct_a_gemm_assembly(tmp_path):
             continue
         sizes = _prefetch_batches(lines)
         assert sizes and all(sz == 24 for sz in sizes), f"{name}: input prefetch is {sizes} loads, raw_ops assumes 24"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_pre_split_kernels_assembly(tmp_path):
+    """Round 5: the pre-split forms of the direct-A kernel (input staged from an image: five or six 16-byte buffer loads per lane
+    and chunk, counted by the ring's waits as `raw_ops = NLD`) and the narrow form without staging (an eight-slot ring of four
+    asm loads per step, every wait vmcnt(28)).  No spills, no ring register touched before its wait, the prefetch batches and the
+    ring waits exactly as counted."""
+    ks = _kernels(_asm("conv_f16x3_da_pre.hip", tmp_path))
+    assert len(ks) == 4, sorted(ks)
+    for name, lines in ks.items():
+        assert not any("scratch_" in ln for ln in lines), f"{name} spills"
+        bad = _audit_no_touch_before_wait(lines)
+        assert not bad, f"{name}: ring registers touched before their wait: {bad[:3]}"
+        body = [ln.strip() for ln in lines]
+        # the image loads: buffer_load_dwordx4 only (no dword loads of an f32 input, no transform left in the kernel)
+        mf = [i for i, ln in enumerate(body) if ln.startswith("v_mfma")]
+        assert not any(re.match(r"global_load_dword\s", ln) for ln in body[mf[0]:mf[-1]]), f"{name}: scalar-dword input loads in the main loop of a pre-split form"
+        mm = re.search(r"da_kernelILi(\d+)ELi(\d+)ELi(\d+)E", name)
+        kt, ntt = int(mm.group(2)), int(mm.group(3))
+        nld = 4 * (32 * ntt + (64 if kt > 0 else 128)) // 256
+        # every run of image loads between two MFMAs / barriers is one prefetch batch of exactly NLD loads
+        runs, n = [], 0
+        for ln in body:
+            if ln.startswith("buffer_load_dwordx4"):
+                n += 1
+            elif (ln.startswith("v_mfma") or ln == "s_barrier") and n:
+                runs.append(n)
+                n = 0
+        assert runs and all(r == nld for r in runs), f"{name}: image prefetch batches {sorted(set(runs))}, raw_ops assumes {nld}"
+        assert sum(1 for ln in body if ln.startswith("v_sin") or ln.startswith("v_rndne")) == 0, f"{name}: snake arithmetic in a pre-split form"
+    ks = _kernels(_asm("conv_f16x3_dapn.hip", tmp_path))
+    assert len(ks) == 1, sorted(ks)
+    for name, lines in ks.items():
+        assert not any("scratch_" in ln for ln in lines), f"{name} spills"
+        bad = _audit_no_touch_before_wait(lines)
+        assert not bad, f"{name}: ring registers touched before their wait: {bad[:3]}"
+        body = [ln.strip() for ln in lines]
+        R = 8
+        waits = [i for i, ln in enumerate(body) if ln.startswith(f"s_waitcnt vmcnt({4 * (R - 1)})")]
+        assert len(waits) == R, f"{name}: {len(waits)} ring waits in the unrolled round of {R}"
+        for a0, a1 in zip(waits, waits[1:]):
+            nmem = sum(1 for ln in body[a0:a1] if re.match(r"(global|buffer|flat|scratch)_(load|store|atomic)", ln))
+            assert nmem == 4, f"{name}: {nmem} vector-memory operations between two ring waits, the waits assume 4"
+            nmf = sum(1 for ln in body[a0:a1] if ln.startswith("v_mfma"))
+            assert nmf == 3, f"{name}: {nmf} MFMAs per step"
