@@ -12,14 +12,14 @@ LIB_PATH = os.path.join(LIB_DIR, "libkokorox_hip.so")
 # the stand-alone kernel hooks of tests/ (include/kokorox_hip_test.h): a library of its own, linked against the one above
 TEST_LIB_PATH = os.path.join(LIB_DIR, "libkokorox_hip_test.so")
 TEST_SOURCES = ["test_hooks.hip"]
-SOURCES = ["conv_mfma.hip", "conv_f16x3.hip", "conv_f16x3_da.hip", "conv_f16x3_da_p1.hip", "conv_f16x3_da_w2.hip", "conv_f16x3_da_s16.hip", "conv_f16x3_da_pre.hip", "conv_f16x3_pre.hip", "conv_f16x3_dapn.hip", "conv_f16x3_dag.hip", "kernels_misc.hip", "model.hip", "api.hip", "dispatcher.hip", "onnx_import.cpp"]
+SOURCES = ["conv_mfma.hip", "conv_f16x3.hip", "conv_f16x3_da.hip", "conv_f16x3_da_p1.hip", "conv_f16x3_da_w2.hip", "conv_f16x3_da_s16.hip", "conv_f16x3_da_f8.hip", "conv_f16x3_da_pre.hip", "conv_f16x3_pre.hip", "conv_f16x3_dapn.hip", "conv_f16x3_dag.hip", "kernels_misc.hip", "model.hip", "api.hip", "dispatcher.hip", "onnx_import.cpp"]
 HEADERS = ["kx_common.h", "kx_error.h", "conv_epilogue.h", "conv_f16x3_common.h"]
 _PUB = os.path.join("..", "..", "include", "kokorox_hip.h")
 _PUB_TEST = os.path.join("..", "..", "include", "kokorox_hip_test.h")
 # sources that include another source (the direct-A instantiation units) or a header of their own: rebuilt when that one changes
 EXTRA_DEPS = {"model.hip": ["onnx_import.h", "model.h", _PUB], "api.hip": ["model.h", "kx_handle.h", "api_guard.h", _PUB],
               "dispatcher.hip": ["model.h", "kx_handle.h", "dispatcher_core.h", _PUB],
-              "test_hooks.hip": ["model.h", "kx_handle.h", "api_guard.h", _PUB, _PUB_TEST], "onnx_import.cpp": ["onnx_import.h"], "conv_f16x3_da_p1.hip": ["conv_f16x3_da.hip"], "conv_f16x3_da_w2.hip": ["conv_f16x3_da.hip"], "conv_f16x3_da_s16.hip": ["conv_f16x3_da.hip"], "conv_f16x3_da_pre.hip": ["conv_f16x3_da.hip"]}
+              "test_hooks.hip": ["model.h", "kx_handle.h", "api_guard.h", _PUB, _PUB_TEST], "onnx_import.cpp": ["onnx_import.h"], "conv_f16x3_da_p1.hip": ["conv_f16x3_da.hip"], "conv_f16x3_da_w2.hip": ["conv_f16x3_da.hip"], "conv_f16x3_da_s16.hip": ["conv_f16x3_da.hip"], "conv_f16x3_da_f8.hip": ["conv_f16x3_da.hip"], "conv_f16x3_da_pre.hip": ["conv_f16x3_da.hip"]}
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-result"]
 
 

@@ -342,8 +342,8 @@ int kx_arena_bytes(kx_model* m, int64_t* out3) {
 
 int kx_set_conv_mode(kx_model* m, int mode) {
     return guarded(m, [&](Model& M) {
-        KX_REQUIRE(mode == kx::CONV_F32 || mode == kx::CONV_F16X3 || mode == kx::CONV_F16 || mode == kx::CONV_BF16,
-                   "conv mode must be 0 (f32 MFMA), 1 (f16x3 split MFMA), 4 (f16, reduced precision) or 5 (bf16, reduced precision)");
+        KX_REQUIRE(mode == kx::CONV_F32 || mode == kx::CONV_F16X3 || mode == kx::CONV_F16 || mode == kx::CONV_BF16 || mode == kx::CONV_F16F8,
+                   "conv mode must be 0 (f32 MFMA), 1 (f16x3 split MFMA), 4 (f16, reduced precision), 5 (bf16, reduced precision) or 6 (f16f8: 8-bit cross terms)");
         M.set_conv_mode(mode);
     });
 }

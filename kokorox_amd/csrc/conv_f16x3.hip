@@ -678,6 +678,45 @@ void launch_image_to_bf16(const void* w16, void* dst, size_t n_halves, hipStream
     KX_HIP(hipGetLastError());
 }
 
+// ---- f16f8 mode: the weights' cross-term operands (layout: kx_common.h, launch_pack_conv8x) -------------------------------
+size_t packed_conv8x_bytes(int rows, int Cin, int K) {
+    const size_t tiles = (rows + 127) / 128, chunks = (Cin + CK16 - 1) / CK16, groups = (K + 3) / 4;
+    return tiles * chunks * groups * 4 * 128 * 32;
+}
+
+__global__ void pack_conv8x_kernel(const _Float16* w16, unsigned* dst, int K, long total_dwords) {
+    const int NG = (K + 3) / 4;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total_dwords; e += (long)gridDim.x * blockDim.x) {
+        long q = e;
+        const int d = q % 4; q /= 4;
+        const int sl = q % 2; q /= 2;
+        const int row = q % 128; q /= 128;
+        const int g = q % 4; q /= 4;
+        const int mg = q % NG; q /= NG;  // q: row tile x chunk
+        const int tap = 4 * mg + 2 * (g >> 1) + sl, hh = g & 1;
+        unsigned out = 0u;
+        if (tap < K) {
+            // split-f16 image [ct][ch][tap][hi|lo][hh][128][8]
+            const _Float16* src = w16 + (((q * K + tap) * 2) * 2 * 128) * 8;
+            const _Float16* ph = src + ((0 * 2 + hh) * 128L + row) * 8 + 2 * d;
+            const _Float16* pl = src + ((1 * 2 + hh) * 128L + row) * 8 + 2 * d;
+            const float h0 = __builtin_amdgcn_fmed3f((float)ph[0] * 0.0625f, -448.f, 448.f), h1 = __builtin_amdgcn_fmed3f((float)ph[1] * 0.0625f, -448.f, 448.f);
+            const float l0 = __builtin_amdgcn_fmed3f((float)pl[0] * 128.f, -448.f, 448.f), l1 = __builtin_amdgcn_fmed3f((float)pl[1] * 128.f, -448.f, 448.f);
+            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(l0, l1, 0, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(h0, h1, pk, true);
+            out = (unsigned)pk;
+        }
+        dst[e] = out;
+    }
+}
+
+void launch_pack_conv8x(const void* w16, void* dst, int rows, int Cin, int K, hipStream_t s) {
+    const long total = (long)(packed_conv8x_bytes(rows, Cin, K) / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_conv8x_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const _Float16*>(w16), static_cast<unsigned*>(dst), K, total);
+    KX_HIP(hipGetLastError());
+}
+
 void launch_pack_convT16(const float* w, void* dst, int Cin, int Cout, int sd, int BM, float wscale, hipStream_t s) {
     const long total = (long)packed_conv16_halves(sd * Cout, Cin, 2, BM) / 2;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);

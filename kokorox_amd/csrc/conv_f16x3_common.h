@@ -51,6 +51,27 @@ __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi_pk, 
     lo_pk = __builtin_bit_cast(unsigned, l2);
 }
 
+// f16f8 mode: hi_pk as split_pair; x_pk = the pair's 8-bit operands of the two cross terms of a product,
+// [e4m3(v0), e4m3(v1), e4m3(2^11 (v0 - hi0)), e4m3(2^11 (v1 - hi1))], each clamped to e4m3's finite range (the conversion
+// itself does not saturate).  2^11: a residual is at most half an ulp of its f16 high part, so for |v| in [2^-6, 448] both
+// images lie in e4m3's normal range; outside it the cross terms lose bits, never the product's leading term.
+__device__ __forceinline__ void split_pair_f8(float v0, float v1, unsigned& hi_pk, unsigned& x_pk) {
+    float2v v;
+    v[0] = __builtin_amdgcn_fmed3f(v0, -65504.f, 65504.f);
+    v[1] = __builtin_amdgcn_fmed3f(v1, -65504.f, 65504.f);
+    const half2v h2 = __builtin_convertvector(v, half2v);
+    float d0 = (v[0] - (float)h2[0]) * 2048.f;
+    float d1 = (v[1] - (float)h2[1]) * 2048.f;
+    asm volatile("" : "+v"(d0));  // (keeps the SLP vectoriser from packing the pair: see split_pair)
+    const float c0 = __builtin_amdgcn_fmed3f(v0, -448.f, 448.f), c1 = __builtin_amdgcn_fmed3f(v1, -448.f, 448.f);
+    d0 = __builtin_amdgcn_fmed3f(d0, -448.f, 448.f);
+    d1 = __builtin_amdgcn_fmed3f(d1, -448.f, 448.f);
+    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(c0, c1, 0, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(d0, d1, pk, true);
+    hi_pk = __builtin_bit_cast(unsigned, h2);
+    x_pk = (unsigned)pk;
+}
+
 template <int ACT>
 __device__ __forceinline__ float in_act(float y, float slope, float al, float ial) {
     if (ACT == ACT_SNAKE) return fmaf(ial, sin_sq(al * y), y);

@@ -75,9 +75,66 @@ bool conv16_use_da(int BM, int K, int dil, int stride, int merged) {
 // otherwise repeat the transform of the same window (profiles/r05_pmc_sq_*.txt: 9 - 14 vector instructions per MFMA there).
 // BF (with P1 only): the reduced-precision form on bf16 instead of f16 (KOKOROX_CONV=bf16: the dtype BASELINE configs[2] names):
 // activations rounded to bf16 (round to nearest even) in the staged image, weights from a bf16 image, v_mfma_f32_32x32x16_bf16.
-template <int ACT, int KT, int NTT, bool P1, bool W2 = false, bool S16 = false, bool PRE = false, bool BF = false>
+// F8 (with S16 only; KOKOROX_CONV=f16f8, opt-in): the two cross terms a_lo b_hi + a_hi b_lo of a product go to
+// v_mfma_scale_f32_16x16x128_f8f6f4 on e4m3 images of the four operands (twice the f16 rate: one instruction carries both cross terms
+// of 16 channels x 4 taps), a_hi b_hi stays on v_mfma_f32_16x16x32_f16: 2 MFMA-equivalents per product instead of 3, at ~2^-17 per
+// product instead of 2^-22 (tools/probes/mfma_f8mix.hip: 1.52 x in a bare loop; see "S16 form, f16f8" below).
+//
+// Schedule of that loop: which pair-steps carry a cross-term group, and the hand-counted ages of its ring slots.
+template <int KT, int RH, int RC, int RAW>
+struct F8Sched {
+    static constexpr int HS = (KT - 1) / 2, NG = (KT + 1) / 4, NC = 2 * NG;
+    // cross-term use c of a super-chunk (c < NG: group c of the even chunk, else group c - NG of the odd chunk) rides on pair-step:
+    // the even chunk's on 0, 2, .. (buffer 0, before barrier 2), the odd chunk's on the last NG even ones (buffer 1, behind barrier 1)
+    static constexpr int cross_of(int p) {
+        if (p & 1) return -1;
+        if (p <= 2 * (NG - 1)) return p / 2;
+        if (p >= KT - 1 - 2 * (NG - 1)) return NC - 1 - (KT - 1 - p) / 2;
+        return -1;
+    }
+    // vector-memory operations issued between the refill of a slot and the wait that hands it on, in the steady state
+    // (kind 0: the hi slot of pair-step id; kind 1: the cross slot of use id).  Program order of a super-chunk: per pair-step
+    // [p == HS: the input prefetch] [the waits] .. [hi refill: 2 loads] [cross refill: 4 loads]; the input prefetch behind barrier 3.
+    static constexpr int age(int kind, int id) {
+        int n = 0, result = -1;
+        int st_h[3 * KT + 8] = {}, st_x[3 * NC + 8] = {};
+        for (int sc = 0; sc < 2; ++sc) {
+            for (int p = 0; p < KT; ++p) {
+                if (p == HS) n += RAW;
+                if (sc == 1) {
+                    if (kind == 0 && p == id) result = n - st_h[KT + p];
+                    if (kind == 1 && cross_of(p) == id) result = n - st_x[NC + id];
+                }
+                n += 2;
+                st_h[p + RH <= KT - 1 ? sc * KT + p + RH : (sc + 1) * KT + p % RH] = n;
+                const int c = cross_of(p);
+                if (c >= 0) {
+                    n += 4;
+                    st_x[sc * NC + c + RC] = n;
+                }
+            }
+            n += RAW;
+        }
+        return result < 63 ? result : 63;
+    }
+    // matrix-pipe time of blocks [first, first + n) of a super-chunk (NB blocks per pair-step) in units of one f16 MFMA pair:
+    // 3 with a cross group, 1 without
+    static constexpr int cum(int NB, int first, int n) {
+        int t = 0;
+        for (int r = 0; r < n; ++r) t += cross_of((first + r) / NB) >= 0 ? 3 : 1;
+        return t;
+    }
+    // half-units (of HU) of the transform done before block rel of the phase that starts at block `first` and has NA blocks:
+    // proportional to matrix-pipe time, none in the first I0 blocks
+    static constexpr int hu_before(int NB, int NA, int HU, int first, int I0, int rel) {
+        return rel > I0 ? ((cum(NB, first, rel) - cum(NB, first, I0)) * HU) / (cum(NB, first, NA) - cum(NB, first, I0)) : 0;
+    }
+};
+
+template <int ACT, int KT, int NTT, bool P1, bool W2 = false, bool S16 = false, bool PRE = false, bool BF = false, bool F8 = false>
 __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_da_kernel(const ConvArgs a) {
     static_assert(!BF || P1, "BF: a form of the reduced-precision kernels only");
+    static_assert(!F8 || (S16 && KT % 4 == 3), "F8: a form of the S16 loop; tap groups of four with one padding slot");
     static_assert(!PRE || (!P1 && !S16 && ACT == ACT_NONE), "PRE: the activation lives in the image; f16x3 forms on 32x32x16 only");
     static_assert(!W2 || (KT >= 3 && (KT & 1) && NTT == 8), "W2: odd compile-time tap counts on the 256-column tile");
     static_assert(!S16 || (KT >= 3 && (KT & 1) && !P1 && !W2), "S16: odd compile-time tap counts, three MFMAs per product, 4 x 1 waves");
@@ -116,6 +173,8 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
             };
             hi_pk = rne(v0) | (rne(v1) << 16);
             lo_pk = 0u;
+        } else if constexpr (F8) {
+            split_pair_f8(v0, v1, hi_pk, lo_pk);  // (the "lo" planes of the image hold the 8-bit operands of the cross terms)
         } else {
             split_pair(v0, v1, hi_pk, lo_pk);
         }
@@ -545,7 +604,7 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
     u32x4 ah0 = {0, 0, 0, 0}, al0 = {0, 0, 0, 0}, ah1 = {0, 0, 0, 0}, al1 = {0, 0, 0, 0}, ah2 = {0, 0, 0, 0}, al2 = {0, 0, 0, 0};
     u32x4 a2h[2][2] = {}, a2l[2][2] = {};  // W2 / S16: [slot][row block]
     if constexpr (W2) load_A2(0, a2h[1], a2l[1]);  // (a chunk's first step arrives in slot 1, see below)
-    if constexpr (S16) load_A16(0, a2h[1], a2l[1]);  // (a super-chunk's first pair likewise)
+    if constexpr (S16 && !F8) load_A16(0, a2h[1], a2l[1]);  // (a super-chunk's first pair likewise)
     if constexpr (!W2 && !S16) {
     load_A(0, ah0, al0);
     load_A(1, ah1, al1);
@@ -570,7 +629,198 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
         age0 = age1 = age2 = raw_ops;
     }
 
-    if constexpr (S16) {
+    if constexpr (S16 && F8) {
+        // ================= S16 form, f16f8: a_hi b_hi on v_mfma_f32_16x16x32_f16, the cross terms on the 8-bit scaled MFMA =========
+        // The frame is the S16 form's below (super-chunks of two chunks, KT pair-steps, the three barriers, the transform dealt out
+        // behind the MFMAs); what changes:
+        //   * a pair-step's blocks run TWO f16 MFMAs (a_hi b_hi of the wave's two row blocks) instead of six;
+        //   * the cross terms of a chunk (16 channels x KT taps) are NG = (KT + 1) / 4 groups of 4 taps; one
+        //     v_mfma_scale_f32_16x16x128_f8f6f4 per group, block and row block sums a_lo b_hi + a_hi b_lo over the group's 64
+        //     (channel, tap) pairs: K = 128 = k-group g (octet g & 1, tap pair g >> 1) x 2 slots of 16 B x [2^7 lo | 2^-4 hi] against
+        //     [hi | 2^11 lo] of the activations, all e4m3, the common 2^7 undone by the A operand's block scale (2^-7);
+        //     the last group's last slot is padding (zero weights; the lane re-reads the slot before it, finite by construction);
+        //   * the even chunk's groups ride on pair-steps 0, 2, .. (buffer 0 is read until barrier 2), the odd chunk's on the last NG
+        //     even pair-steps (buffer 1 is complete from barrier 1 on); the straddling pair-step (HS, odd) carries none;
+        //   * rings: RH hi slots of 8 registers (pair-step p in slot p % RH, refilled behind its last block with pair-step p + RH, or
+        //     with the NEXT super-chunk's pair-step p % RH -- no slot is shared by the last and the first pair-step, so nothing is
+        //     moved), RC cross slots of 16 registers (use c in slot c % RC); every vector-memory operation of the loop is
+        //     unconditional, the ages are those of F8Sched::age.
+        // Per accumulator: cross terms of a group, then the pair's a_hi b_hi; groups and taps ascending.
+        static_assert(W64, "S16: the 64-column window of the unrolled forms");
+        constexpr int NB = 2 * NT, HS = (KT - 1) / 2, TB = KT * NB, NA = HS * NB, SB0 = (HS + 1) * NB;
+#ifndef KX_F8_RH
+#define KX_F8_RH ((KT - 1) % 3 != 0 ? 3 : 4)
+#endif
+#ifndef KX_F8_RC
+#define KX_F8_RC (NT == 6 ? 1 : 2)  // (the 192-column tile has 16 registers for one cross slot, not 32 for two)
+#endif
+        constexpr int RH = KX_F8_RH, RC = KX_F8_RC;
+        using FS = F8Sched<KT, RH, RC, raw_ops>;
+        constexpr int NG = FS::NG, NC = FS::NC;
+        static_assert(RH <= KT && (KT - 1) % RH != 0 && NC % RC == 0, "f16f8: static ring slots");
+        static_assert(2 * (NG - 1) <= HS && KT - 1 - 2 * (NG - 1) >= HS && (HS & 1), "f16f8: cross groups inside their buffer's phase");
+        const int n_super = n_chunks >> 1;
+        const int d_norm = tau16 ? dil : 0, d_str = tau16 ? XBUF - (KT - 1) * dil : 0;
+        int d_x2 = tau16 ? 2 * dil : 0;  // a lane's first slot of a group: tap 4 m + 2 (lane >> 5)
+        int d_xl = tau16 ? 0 : dil;      // its second slot in a chunk's LAST group: the next tap, or (padding) the same one again
+        using v8i = __attribute__((ext_vector_type(8))) int;
+        u32x4 hs[RH][2], xs[RC][4];
+        const uint4* wxlane = reinterpret_cast<const uint4*>(a.w8x) + (long)ct * n_chunks * NG * 1024 + ((lane >> 4) * 128 + wave * 32 + r16) * 2;
+        auto load_H = [&](int s0, u32x4 (&xh)[2]) __attribute__((always_inline)) {
+            const uint4* pp = wlane16 + (long)(s0 < n_steps - 2 ? s0 : n_steps - 2) * tap_units;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xh[0]) : "v"(pp) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:256" : "=v"(xh[1]) : "v"(pp) : "memory");
+        };
+        auto load_X = [&](int chunk, const int m, u32x4 (&x)[4]) __attribute__((always_inline)) {
+            const uint4* pp = wxlane + ((long)(chunk < n_chunks ? chunk : n_chunks - 1) * NG + m) * 1024;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x[0]) : "v"(pp) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(x[1]) : "v"(pp) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(x[2]) : "v"(pp) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:528" : "=v"(x[3]) : "v"(pp) : "memory");
+        };
+        static_for<0, RH>([&](auto qc) __attribute__((always_inline)) { load_H(2 * decltype(qc)::value, hs[decltype(qc)::value]); });
+        static_for<0, RC>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int c = decltype(qc)::value;
+            load_X(c >= NG ? 1 : 0, c >= NG ? c - NG : c, xs[c]);
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (once per tile: the ages of the loop are steady-state ages)
+        int xl_it = h16 * XWp + r16;
+        int dil_it = dil;
+        half8 fh[2];
+        v8i fx[2];
+        auto load_blk_h = [&](const int p, const int nb, half8& fhx) __attribute__((always_inline)) {
+            const int f0 = 2 * p, b0 = f0 >= KT ? 1 : 0, tp = f0 - b0 * KT;
+            const uint4* xt = Xs + (xl_it + b0 * XBUF + tp * dil_it + (f0 == KT - 1 ? d_str : d_norm) + nb * 16);
+            fhx = *reinterpret_cast<const half8*>(xt);
+        };
+        auto load_blk_x = [&](const int c, const int nb, v8i& fxx) __attribute__((always_inline)) {
+            const int b0 = c >= NG ? 1 : 0, m = c - b0 * NG;
+            const uint4* xt = Xs + (xl_it + 2 * XWp + b0 * XBUF + 4 * m * dil_it + d_x2 + nb * 16);
+            const uint4 u0 = *xt, u1 = *(xt + (m == NG - 1 ? d_xl : dil_it));
+            fxx = v8i{(int)u0.x, (int)u0.y, (int)u0.z, (int)u0.w, (int)u1.x, (int)u1.y, (int)u1.z, (int)u1.w};
+        };
+#ifndef KX_F8_I0A_LONG
+#define KX_F8_I0A_LONG 40
+#endif
+#ifndef KX_F8_I0A_MID
+#define KX_F8_I0A_MID 16
+#endif
+#ifndef KX_F8_I0B
+#define KX_F8_I0B 8
+#endif
+        constexpr int I0A = (KT >= 9 ? KX_F8_I0A_LONG : KX_F8_I0A_MID) * NT / 8, I0B = KX_F8_I0B * NT / 8;
+        static_assert(I0A < NA && I0B < NA, "f16f8: the transform needs blocks to ride on");
+#ifndef KX_F8_G
+#define KX_F8_G 2
+#endif
+        constexpr int G = KX_F8_G;
+        static_assert(NB % G == 0, "f16f8: a scheduling region lies inside one pair-step");
+        load_blk_h(0, 0, fh[0]);
+        load_blk_x(0, 0, fx[0]);
+        for (int sc = 0; sc < n_super; ++sc) {
+            const int ch0 = 2 * sc, P0 = sc * KT;
+            asm volatile("" : "+v"(xl_it), "+s"(dil_it), "+v"(d_x2), "+v"(d_xl));
+            static_for<0, TB>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int p = i / NB, nb = i % NB, sl = p % RH, e = i & 1, ip = i + 1;
+                constexpr int c = FS::cross_of(p), xsl = c >= 0 ? c % RC : 0;
+                if constexpr (nb == 0) {
+                    if constexpr (p == HS) {
+                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier 1
+                        load_raw(ch0 + 2 < n_chunks ? ch0 + 2 : n_chunks - 1);
+                        load_blk_h(p, 0, fh[e]);
+                    }
+                    if constexpr (p == HS + 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier 2
+                    constexpr int ag_h = FS::age(0, p), ag_x = c >= 0 ? FS::age(1, c) : 63;
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ag_h < ag_x ? ag_h : ag_x) : "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("" : "+v"(hs[sl][0]), "+v"(hs[sl][1]));
+                    if constexpr (c >= 0) asm volatile("" : "+v"(xs[xsl][0]), "+v"(xs[xsl][1]), "+v"(xs[xsl][2]), "+v"(xs[xsl][3]));
+                }
+                const half8 a0h = __builtin_bit_cast(half8, hs[sl][0]), a1h = __builtin_bit_cast(half8, hs[sl][1]);
+                // the next block's fragments (not across barrier 1: the image they read is still being written)
+                if constexpr (ip < TB && ip != HS * NB) {
+                    load_blk_h(ip / NB, ip % NB, fh[e ^ 1]);
+                    if constexpr (FS::cross_of(ip / NB) >= 0) load_blk_x(FS::cross_of(ip / NB), ip % NB, fx[e ^ 1]);
+                }
+                if constexpr (i % G == 0) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (c >= 0) {
+                    const v8i x0 = v8i{(int)xs[xsl][0][0], (int)xs[xsl][0][1], (int)xs[xsl][0][2], (int)xs[xsl][0][3],
+                                       (int)xs[xsl][1][0], (int)xs[xsl][1][1], (int)xs[xsl][1][2], (int)xs[xsl][1][3]};
+                    const v8i x1 = v8i{(int)xs[xsl][2][0], (int)xs[xsl][2][1], (int)xs[xsl][2][2], (int)xs[xsl][2][3],
+                                       (int)xs[xsl][3][0], (int)xs[xsl][3][1], (int)xs[xsl][3][2], (int)xs[xsl][3][3]};
+                    // (A, B: e4m3; block scales 2^-7 on A, 1 on B)
+                    acc16[0][nb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(x0, fx[e], acc16[0][nb], 0, 0, 0, 0x78787878, 0, 0x7f7f7f7f);
+                    acc16[1][nb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(x1, fx[e], acc16[1][nb], 0, 0, 0, 0x78787878, 0, 0x7f7f7f7f);
+                }
+                acc16[0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, fh[e], acc16[0][nb], 0, 0, 0);
+                acc16[1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, fh[e], acc16[1][nb], 0, 0, 0);
+                // half-units of the transform riding on this block: phase A -> the odd chunk into buffer 1, phase B -> the next
+                // even chunk into buffer 0 (in the last super-chunk: stale registers into an image nobody reads)
+                constexpr bool inA = i < NA, inB = i >= SB0;
+                constexpr int first = inA ? 0 : SB0, rel = inA ? i : i - SB0, I0 = inA ? I0A : I0B;
+                constexpr int h0 = (inA || inB) ? FS::hu_before(NB, NA, HU, first, I0, rel) : 0;
+                constexpr int h1 = (inA || inB) ? FS::hu_before(NB, NA, HU, first, I0, rel + 1) : 0;
+                static_assert(h1 - h0 <= 2, "at most two half-units per block");
+                uint4* Xdst = Xs + (inA ? 1 : 0) * XBUF;
+                if constexpr (h1 > h0) {
+                    xform_a(h0 / 2, h0 & 1, 0);
+                    xform_b();
+                    xform_c(h0 / 2, h0 & 1, Xdst, 0);
+                }
+                if constexpr (h1 > h0 + 1) {
+                    xform_a((h0 + 1) / 2, (h0 + 1) & 1, 0);
+                    xform_b();
+                    xform_c((h0 + 1) / 2, (h0 + 1) & 1, Xdst, 0);
+                }
+                if constexpr (i % G == G - 1) {  // the pipeline of the region: its half-units spread over its MFMAs by their duration
+                    constexpr int ig = i - (G - 1);
+                    constexpr bool gA = ig < NA, gB = ig >= SB0;
+                    constexpr int gfirst = gA ? 0 : SB0, grel = gA ? ig : ig - SB0, gI0 = gA ? I0A : I0B;
+                    constexpr int hg0 = (gA || gB) ? FS::hu_before(NB, NA, HU, gfirst, gI0, grel) : 0;
+                    constexpr int nh = h1 > hg0 ? h1 - hg0 : 0;
+                    constexpr int units = G * (c >= 0 ? 6 : 2);  // (16-cycle units: a scaled MFMA is two)
+                    constexpr int per = nh > 0 ? (nh * (UVI + 7) + units - 1) / units : 0;
+#pragma unroll
+                    for (int tg = 0; tg < G; ++tg) {
+                        if (tg > 0) __builtin_amdgcn_sched_group_barrier(0x100, c >= 0 ? 3 : 1, 0);
+                        if (c >= 0) {
+#pragma unroll
+                            for (int k2 = 0; k2 < 2; ++k2) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                if (per > 0) __builtin_amdgcn_sched_group_barrier(0x002, 2 * per, 0);
+                            }
+                        }
+#pragma unroll
+                        for (int k2 = 0; k2 < 2; ++k2) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            if (per > 0) __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (nb == NB - 1) {  // refills: the hi slot with pair-step p + RH (or the next super-chunk's p % RH) ..
+                    load_H(2 * (P0 + (p + RH <= KT - 1 ? p + RH : KT + p % RH)), hs[sl]);
+                    if constexpr (c >= 0) {  // .. the cross slot with use c + RC
+                        constexpr int cn = c + RC, cw = cn >= NC ? cn - NC : cn;
+                        load_X(ch0 + (cn >= NC ? 2 : 0) + (cw >= NG ? 1 : 0), cw >= NG ? cw - NG : cw, xs[xsl]);
+                    }
+                }
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier 3
+            load_raw(ch0 + 3 < n_chunks ? ch0 + 3 : n_chunks - 1);
+            load_blk_h(0, 0, fh[0]);
+            load_blk_x(0, 0, fx[0]);
+        }
+        (void)n_super;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (the slots stay reserved until here: the last refills are still landing when the loop ends)
+        asm volatile("" ::"v"(hs[0][0]), "v"(hs[0][1]), "v"(hs[1][0]), "v"(hs[1][1]), "v"(hs[RH - 1][0]), "v"(hs[RH - 1][1]));
+        if constexpr (RH > 3) asm volatile("" ::"v"(hs[2][0]), "v"(hs[2][1]));
+        asm volatile("" ::"v"(xs[0][0]), "v"(xs[0][1]), "v"(xs[0][2]), "v"(xs[0][3]));
+        if constexpr (RC > 1) asm volatile("" ::"v"(xs[RC - 1][0]), "v"(xs[RC - 1][1]), "v"(xs[RC - 1][2]), "v"(xs[RC - 1][3]));
+        static_assert(RH >= 2 && RH <= 4 && RC >= 1 && RC <= 2, "f16f8: ring sizes the code above spells out");
+    } else if constexpr (S16) {
         // ================= S16 form: the unrolled loop on v_mfma_f32_16x16x32_f16 ================================
         // Why (profiles/r03_mfma_shape_probe.txt, r03_s16_form.txt): the chip is power-limited under this kernel, and the same FLOPs
         // issued as 16x16x32 instead of 32x32x16 hold a higher clock (-9.5 % wall time in a bare loop with the same LDS operand
@@ -1163,9 +1413,15 @@ constexpr bool DA_S16 = true;
 constexpr bool DA_S16 = false;
 #endif
 
+#ifdef KX_DA_F8
+constexpr bool DA_F8 = true;
+#else
+constexpr bool DA_F8 = false;
+#endif
+
 template <int ACT, int KT, int NTT, bool W2X = DA_W2, bool PREX = false, bool BFX = false>
 static void launch_da_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
-    auto kern = conv1d_f16x3_da_kernel<ACT, KT, NTT, DA_P1, W2X, DA_S16, PREX, BFX>;
+    auto kern = conv1d_f16x3_da_kernel<ACT, KT, NTT, DA_P1, W2X, DA_S16, PREX, BFX, DA_F8>;
     constexpr int BN = 32 * NTT;
     // two input buffers (48 / 32 KiB), and never less than the statistics scratch of the epilogue (4 waves x 8.25 KiB)
     constexpr size_t lds_x = 16 * (size_t)2 * 4 * (BN + 128), lds_scr = 4 * 32 * 33 * sizeof(float2);
@@ -1203,6 +1459,23 @@ void launch_conv1d_f16x3_da_pre(const ConvArgs& a, int B, int max_cols, hipStrea
     } else {
         if (w64) launch_da_inst<ACT_NONE, 3, 4, false, true>(a, B, max_cols, s);
         else launch_da_inst<ACT_NONE, 0, 4, false, true>(a, B, max_cols, s);
+    }
+}
+#elif defined(KX_DA_F8)
+// The f16f8 forms of the S16 loop (conv_f16x3_da_f8.hip defines KX_DA_S16 and KX_DA_F8 and includes this file): the S16 shapes
+// whose tap count is 3 mod 4 (11 and 7: all of them), when the layer carries an 8-bit cross image (ConvArgs::w8x, CONV_F16F8).
+bool conv16_da_f8_shape(int K, int dil) { return (K == 11 || K == 7) && (K - 1) * dil <= 64; }
+void launch_conv1d_f16x3_da_f8(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn) {
+    KX_REQUIRE(a.w8x != nullptr && conv16_da_f8_shape(a.K, a.dil) && a.act == ACT_SNAKE && a.stride == 1 && a.merge_T == 0 && !a.prec1 &&
+                   a.n_chunks16 >= 2 && (a.n_chunks16 & 1) == 0,
+               "conv1d f16x3 da f8: launch not eligible");
+    KX_REQUIRE(bn == 192 || bn == 128, "conv1d f16x3 da f8: tile of 192 or 128 columns");
+    if (a.K == 11) {
+        if (bn == 192) launch_da_inst<ACT_SNAKE, 11, 6>(a, B, max_cols, s);
+        else launch_da_inst<ACT_SNAKE, 11, 4>(a, B, max_cols, s);
+    } else {
+        if (bn == 192) launch_da_inst<ACT_SNAKE, 7, 6>(a, B, max_cols, s);
+        else launch_da_inst<ACT_SNAKE, 7, 4>(a, B, max_cols, s);
     }
 }
 #elif defined(KX_DA_S16)
@@ -1322,7 +1595,8 @@ void launch_conv1d_f16x3_da(const ConvArgs& a, int B, int max_cols, hipStream_t 
     // 7 / 11-tap snake convs: the 16x16x32 form on its 192- or 128-column tile (conv16_pick_tile chose bn and the 64-column
     // statistics slots for it by the same predicate)
     if (conv16_da_s16_shape(128, a.K, a.dil, a.stride, a.act, a.n_chunks16, a.merge_T > 0, a.prec1 != 0)) {
-        launch_conv1d_f16x3_da_s16(a, B, max_cols, s, bn == 128 ? 128 : 192);
+        if (a.w8x && conv16_da_f8_shape(a.K, a.dil)) launch_conv1d_f16x3_da_f8(a, B, max_cols, s, bn == 128 ? 128 : 192);  // (CONV_F16F8)
+        else launch_conv1d_f16x3_da_s16(a, B, max_cols, s, bn == 128 ? 128 : 192);
         return;
     }
     KX_REQUIRE(bn != 192, "conv1d f16x3 da: the 192-column tile exists in the S16 form only");

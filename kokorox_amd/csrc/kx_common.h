@@ -104,6 +104,7 @@ struct ConvArgs {
     // f16x3 path (conv_f16x3.hip): split-f16 weight image, 16-channel chunks, 2^-ws to undo the weight scale
     const void* w16;
     const void* w16b;  // the bf16 form of the same image (prec1 == 2 launches of the direct-A kernel swap it in), or null
+    const void* w8x;   // f16f8 mode (CONV_F16F8): the 8-bit image of the weights' cross-term operands (launch_pack_conv8x), or null
     int n_chunks16;
     float w_unscale;
     float x_prescale;  // f16x3: power of two applied to the transformed input before the hi/lo split (w_unscale carries
@@ -173,7 +174,7 @@ void launch_pack_convT(const float* w, float* dst, int Cin, int Cout, int s, int
 size_t packed_conv_floats(int rows, int Cin, int K, int BM);
 
 // f16x3 split path
-enum ConvMode { CONV_F32 = 0, CONV_F16X3 = 1, CONV_F16X3_LDS = 2, CONV_F16X3_DA = 3, CONV_F16 = 4, CONV_BF16 = 5 };  // (2, 3: test hook only: f16x3 kept on the LDS-DMA kernel forms of conv_f16x3.hip / forced through conv_f16x3_da.hip)
+enum ConvMode { CONV_F32 = 0, CONV_F16X3 = 1, CONV_F16X3_LDS = 2, CONV_F16X3_DA = 3, CONV_F16 = 4, CONV_BF16 = 5, CONV_F16F8 = 6 };  // (2, 3: test hook only: f16x3 kept on the LDS-DMA kernel forms of conv_f16x3.hip / forced through conv_f16x3_da.hip)
 void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStream_t s);
 // (act / n_chunks16 / prec1: given, the shapes of the direct-A S16 form get its tiles: 192 or 128 columns, 64-column statistics slots)
 void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int stride, int* bn, int* wn,
@@ -197,6 +198,16 @@ void launch_pack_conv16(const PackSrc& src, void* dst, int Cout, int Cin, int K,
 void launch_pack_convT16(const float* w, void* dst, int Cin, int Cout, int sd, int BM, float wscale, hipStream_t s);
 // a split-f16 weight image (hi + lo = the f32 weight to 22 bits) -> the same layout with bf16(hi + lo) in the hi slots (CONV_BF16)
 void launch_image_to_bf16(const void* w16, void* dst, size_t n_halves, hipStream_t s);
+// f16f8 mode: the cross terms a_lo b_hi + a_hi b_lo of the split product on v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 x e4m3, twice the
+// f16 rate), a_hi b_hi stays on the f16 MFMA.  The weights' side of the cross terms, from a split-f16 image of 128-row tiles:
+// [row tile][chunk16][tap group of 4][k-group g = octet + 2 (tap pair)][128 rows][32 B], the 32 B = two slots of 16 B (taps
+// 4 m + 2 (g >> 1) and + 1; taps >= K are zero), a slot = four dwords [e4m3(2^7 lo(2d)), e4m3(2^7 lo(2d+1)), e4m3(2^-4 hi(2d)),
+// e4m3(2^-4 hi(2d+1))] of the octet's channel pairs d -- byte for byte the partner of the activation image's 8-bit plane
+// (split_pair_f8, conv_f16x3_common.h); the products of a slot carry 2^7 (undone by the instruction's block scale).
+size_t packed_conv8x_bytes(int rows, int Cin, int K);
+void launch_pack_conv8x(const void* w16, void* dst, int rows, int Cin, int K, hipStream_t s);
+bool conv16_da_f8_shape(int K, int dil);  // which of the S16 form's shapes have an f16f8 kernel (conv_f16x3_da_f8.hip)
+void launch_conv1d_f16x3_da_f8(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn);
 
 // ---- everything else (kernels_misc.hip) ----------------------------------------------
 void launch_vec_add(const float* a, const float* b, float* out, int n, hipStream_t s);

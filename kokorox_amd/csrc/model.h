@@ -23,6 +23,7 @@ struct ConvW {
     int up_s = 0, up_cout = 0;  // polyphase transposed conv
     const void* w16 = nullptr;  // split-f16 image (conv_f16x3.hip)
     const void* w16b = nullptr; // bf16 form of it (built when KOKOROX_CONV=bf16 / kx_set_conv_mode(5) is first selected)
+    const void* w8x = nullptr;  // 8-bit cross image of it (f16f8 mode: KOKOROX_CONV=f16f8 / kx_set_conv_mode(6); the S16 form's shapes only)
     int n_chunks16 = 0;
     float unscale = 1.f;        // 2^-ws
     std::string name;           // registry key (diagnostics, kx_set_act_prescale)
@@ -176,7 +177,7 @@ class Model {
     std::mutex mu;
     uint64_t utt_base = 0;
     void set_lanes(int n) { lanes_cfg_ = n < 0 ? 0 : (n > N_LANES ? N_LANES : n); }
-    void set_conv_mode(int mode);  // (mode 5 builds the bf16 weight images on first use)
+    void set_conv_mode(int mode);  // (modes 5 / 6 build the bf16 / 8-bit cross weight images on first use)
     int conv_mode = CONV_F16X3;
     int stft_variant = STFT_ONNX;  // the ONNX export's conv-based STFT pair (what the reference runs)
     int device;

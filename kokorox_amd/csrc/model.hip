@@ -30,7 +30,7 @@ struct CuScope {
 
 Model::Model(int dev, int part, int n_parts) : device(dev), part_(part), n_parts_(n_parts) {
     if (const char* e = getenv("KOKOROX_CONV"))
-        conv_mode = (strcmp(e, "f32") == 0) ? CONV_F32 : (strcmp(e, "f16") == 0 ? CONV_F16 : (strcmp(e, "bf16") == 0 ? CONV_BF16 : CONV_F16X3));
+        conv_mode = (strcmp(e, "f32") == 0) ? CONV_F32 : (strcmp(e, "f16") == 0 ? CONV_F16 : (strcmp(e, "bf16") == 0 ? CONV_BF16 : (strcmp(e, "f16f8") == 0 ? CONV_F16F8 : CONV_F16X3)));
     if (const char* e = getenv("KOKOROX_STFT")) stft_variant = (strcmp(e, "torch") == 0) ? STFT_TORCH : STFT_ONNX;
     // (per-device state of the library -- the per-device turn of the forwards, dynamic-LDS attribute limits, CU counts -- is
     // kept in tables of KX_MAX_DEVICES entries: an id beyond them is refused here, never aliased onto another device's entry)
@@ -501,7 +501,7 @@ void Model::build() {
     convs_[G + "conv_post"] = make_conv(G + "conv_post");
 
     for (auto& kv : convs_) kv.second.name = kv.first;
-    if (conv_mode == CONV_BF16) set_conv_mode(CONV_BF16);  // (KOKOROX_CONV=bf16: the images exist from the start)
+    if (conv_mode == CONV_BF16 || conv_mode == CONV_F16F8) set_conv_mode(conv_mode);  // (KOKOROX_CONV=bf16 / f16f8: the images exist from the start)
     for (auto& kv : lstms_) kv.second.ih.name = kv.first + ".ih";
     KX_HIP(hipMalloc((void**)&fc_dev_, fc_host_.size() * sizeof(FcDesc)));
     owned_.push_back(fc_dev_);
@@ -578,7 +578,7 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     // dry run like every other buffer of the back half; the rule looks at the layer's shape only.
     void* x16 = nullptr;
     long x16_bs = 0;
-    if (conv_mode == CONV_F16X3 && img_arena_ && conv16_pre_shape(w.BM, w.rows, w.K, o.dil, o.stride, o.act, o.in_up2)) {
+    if ((conv_mode == CONV_F16X3 || conv_mode == CONV_F16F8) && img_arena_ && conv16_pre_shape(w.BM, w.rows, w.K, o.dil, o.stride, o.act, o.in_up2)) {
         x16_bs = (long)conv16_pre_image_bytes(w.Cin, in.ld);
         x16 = img_arena_->alloc((size_t)B_ * x16_bs);
     }
@@ -629,13 +629,15 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     a.up_off = o.up_off;
     a.up_reflect = o.up_reflect;
     a.up_cout = w.up_cout ? w.up_cout : 1;
-    const bool f16 = conv_mode == CONV_F16X3 || conv_mode == CONV_F16 || conv_mode == CONV_BF16;
+    const bool f16 = conv_mode == CONV_F16X3 || conv_mode == CONV_F16 || conv_mode == CONV_BF16 || conv_mode == CONV_F16F8;
     // reduced-precision mode (opt-in): the decoder and generator convs that take the direct-A kernel run one f16 MFMA
     // per product; everything upstream of the F0 / N curves (duration head, prosody predictor) and every kernel that is
     // not the direct-A conv (harmonic source, STFT pair, k = 1 GEMMs, conv_post) stays f32-class (hard part 3)
     a.prec1 = (conv_mode == CONV_F16 && p1_region_) ? 1 : ((conv_mode == CONV_BF16 && p1_region_ && w.w16b) ? 2 : 0);
     a.w16 = w.w16;
     a.w16b = w.w16b;
+    // f16f8 mode (opt-in): the layers that carry an 8-bit cross image run two MFMA-equivalents per product instead of three
+    a.w8x = conv_mode == CONV_F16F8 ? w.w8x : nullptr;
     a.n_chunks16 = w.n_chunks16;
     static const int xcd_swz = getenv("KX_XCD_SWIZZLE") ? atoi(getenv("KX_XCD_SWIZZLE")) : 1;
     a.xcd_swizzle = xcd_swz;
@@ -999,6 +1001,20 @@ void Model::set_conv_mode(int mode) {
             owned_.push_back(p);
             launch_image_to_bf16(c.w16, p, nh, stream_);
             c.w16b = p;
+        }
+        KX_HIP(hipStreamSynchronize(stream_));
+    }
+    if (mode == CONV_F16F8) {
+        // 8-bit cross images of the layers the f16f8 kernels take (the S16 form's shapes: 7- and 11-tap snake convs), once
+        KX_HIP(hipSetDevice(device));
+        for (auto& kv : convs_) {
+            ConvW& c = kv.second;
+            if (c.w8x || !c.w16 || c.BM != 128 || c.up_s || !(c.K == 7 || c.K == 11) || c.n_chunks16 < 2 || (c.n_chunks16 & 1)) continue;
+            void* p = nullptr;
+            KX_HIP(hipMalloc(&p, packed_conv8x_bytes(c.rows, c.Cin, c.K)));
+            owned_.push_back(p);
+            launch_pack_conv8x(c.w16, p, c.rows, c.Cin, c.K, stream_);
+            c.w8x = p;
         }
         KX_HIP(hipStreamSynchronize(stream_));
     }

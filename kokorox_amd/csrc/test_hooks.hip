@@ -94,6 +94,8 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
         std::vector<int> lens(B, 1);
         // bit 8 of the mode: stage the input through a pre-split image (conv_f16x3_pre.hip), whatever the layer's row count
         const bool pre = (mode & 0x100) != 0;
+        // bit 9: f16f8 -- the layer gets the 8-bit cross image of its weights (the S16 form's shapes then run the f16f8 kernel)
+        const bool f8 = (mode & 0x200) != 0;
         mode &= 0xff;
         KX_REQUIRE(mode >= kx::CONV_F32 && mode <= kx::CONV_F16X3_DA, "test_conv1d: mode must be 0, 1, 2 or 3");
         KX_REQUIRE(!pre || mode == kx::CONV_F16X3 || mode == kx::CONV_F16X3_DA, "test_conv1d: pre-split images exist for the direct-A kernels only");
@@ -228,6 +230,12 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
                 kx::launch_pack_conv16(src, p16, Cout, Cin, k, BM, std::ldexp(1.0f, ws), nullptr);
             }
             a.w16 = p16;
+            if (f8) {
+                KX_REQUIRE(!transposed && BM == 128, "test_conv1d: f16f8 images exist for 128-row tiles of plain convs");
+                void* p8 = dm.get<unsigned char>(kx::packed_conv8x_bytes(rows, Cin, k));
+                kx::launch_pack_conv8x(p16, p8, rows, Cin, k, nullptr);
+                a.w8x = p8;
+            }
             a.n_chunks16 = (Cin + 15) / 16;
             a.w_unscale = std::ldexp(1.0f, -ws);
             a.x_prescale = 1.0f;

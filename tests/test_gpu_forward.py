@@ -44,7 +44,7 @@ def _inputs(token_counts, seed0=10):
     return ids, styles
 
 
-@pytest.mark.parametrize("mode", [pytest.param(0, id="f32"), pytest.param(1, id="f16x3")])
+@pytest.mark.parametrize("mode", [pytest.param(0, id="f32"), pytest.param(1, id="f16x3"), pytest.param(6, id="f16f8")])
 def test_ragged_batch_matches_oracle(hip_model, oracle, mode):
     from kokorox_amd import hip_koko as hk
     default_mode = hip_model.get_conv_mode()
