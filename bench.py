@@ -67,7 +67,11 @@ def usable_cores() -> int:
 
 
 def dtype_label(conv_mode: int) -> str:
-    """kx_get_conv_mode: 0 f32 MFMA, 1 f16x3 split MFMA (default), 4 reduced precision (KOKOROX_CONV=f16)."""
+    """kx_get_conv_mode: 0 f32 MFMA, 1 f16x3 split MFMA, 6 f16f8 (default), 4 / 5 reduced precision (KOKOROX_CONV=f16 / bf16)."""
+    if conv_mode == 6:
+        return ("f32 in / out, f32 accumulate; products on split operands: f16f8 (a_hi b_hi on f16 MFMAs, the cross terms a_lo b_hi + a_hi b_lo of "
+                "the 7 / 11-tap convs on e4m3 scaled MFMAs: ~17 significant bits per product; every other conv f16x3: ~22) -- wider than the "
+                "bf16 BASELINE configs[2] names, inside the 1e-4 parity band (same test as the f32 and f16x3 modes)")
     if conv_mode == 1:
         return "f32 (f16x3 split MFMA: 3 f16 MFMAs per product on hi/lo halves, f32 accumulate)"
     if conv_mode == 4:
@@ -96,7 +100,7 @@ def pmc_traffic(B, T, F, mode):
     return (None, None) if best is None else (best["traffic_bytes_per_launch"], src)
 
 
-def roofline(f16x3, conv_flops, conv_ms, n_launch, steps, wall, B, T, F, conv_bytes=0.0):
+def roofline(f16x3, conv_flops, conv_ms, n_launch, steps, wall, B, T, F, conv_bytes=0.0, f8=False):
     """Dominant kernel = the BM=128 family of the conv1d implicit-GEMM kernel (HIP events in the library).
 
     achieved = ALGORITHMIC FLOPs (2*Cout*Cin*k*L per launch) / measured time.  In f16x3 mode every
@@ -110,7 +114,12 @@ def roofline(f16x3, conv_flops, conv_ms, n_launch, steps, wall, B, T, F, conv_by
             "f16x3 conv family, implicit GEMM, 3 f16 MFMAs per product: v_mfma_f32_32x32x16_f16, and v_mfma_f32_16x16x32_f16 "
             "in the S16 form that carries the 11-tap convs)" if f16x3
             else "kx::conv1d_mfma_kernel<128,128,2,2> (f32 32x32x2 MFMA implicit GEMM)")
-    traffic, traffic_src = pmc_traffic(B, T, F, "f16x3" if f16x3 else "f32")
+    if f8:
+        kern = ("kx::conv1d_f16x3_da_kernel<ACT,K,NT,P1,W2,S16,PRE,BF,F8> + kx::conv1d_f16x3_dag_kernel + kx::conv1d_f16x3_kernel<128,..> (the "
+                "128-row conv family, implicit GEMM; f16f8 mode: the 7 / 11-tap convs = 64 % of the family's FLOPs run v_mfma_f32_16x16x32_f16 "
+                "for a_hi b_hi + v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3) for the two cross terms = 2 MFMA-equivalents per product, the rest 3 "
+                "f16 MFMAs per product)")
+    traffic, traffic_src = pmc_traffic(B, T, F, "f16f8" if f8 else ("f16x3" if f16x3 else "f32"))
     alg_bytes = conv_bytes / max(n_launch, 1)
     out = {"bound": "mfma", "kernel": kern, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
            "traffic": traffic,
@@ -124,7 +133,10 @@ def roofline(f16x3, conv_flops, conv_ms, n_launch, steps, wall, B, T, F, conv_by
            "algorithmic_gb_per_s": alg_bytes / max(conv_ms / max(n_launch, 1) * 1e-3, 1e-12) / 1e9,
            "launches_per_step": n_launch / max(steps, 1), "avg_launch_ms": conv_ms / max(n_launch, 1),
            "gflop_per_launch": conv_flops / max(n_launch, 1) / 1e9, "kernel_share_of_wall": conv_ms * 1e-3 / wall}
-    if f16x3:
+    if f8:
+        out["peak_note"] = "the dense f16 MFMA peak; the 8-bit instruction of the cross terms runs at twice that rate"
+        out["mfma_issue_factor"] = "2 f16-MFMA-equivalents per product on the 7 / 11-tap convs, 3 elsewhere"
+    elif f16x3:
         out["mfma_issue_factor"] = 3
         out["matrix_pipe_utilisation"] = 3 * ach / peak
     return out
@@ -378,7 +390,7 @@ def replicas_main(a):
     det = m0.profile_detail()
     conv_bytes = float(det[:, 9].sum()) if len(det) else 0.0
     m0.profile_enable(False)
-    rl = roofline(m0.get_conv_mode() in (1, 4), conv_flops, conv_ms, n_launch, a.steps, wall, B, T, F, conv_bytes)
+    rl = roofline(m0.get_conv_mode() in (1, 4, 5, 6), conv_flops, conv_ms, n_launch, a.steps, wall, B, T, F, conv_bytes, f8=m0.get_conv_mode() == 6)
     if rl is not None:
         rl["measured_on"] = f"replica 0 of {N} (device {dev_ids[0]}" + (f", CU partition 0 of {dev_ids.count(dev_ids[0])}" if dev_ids.count(dev_ids[0]) > 1 else "") + ")"
     out = {
@@ -520,7 +532,7 @@ def main():
     n_launch, conv_ms, conv_flops = model.profile_read()
     stats_launches, stats_bytes = model.profile_aux()
     conv_mode = model.get_conv_mode()
-    f16x3 = conv_mode in (1, 4, 5)  # all run the 16-bit matrix pipe (modes 4 / 5 = the opt-in reduced precision, labelled as such)
+    f16x3 = conv_mode in (1, 4, 5, 6)  # all run the 16-bit matrix pipe (modes 4 / 5 = the opt-in reduced precision, labelled as such)
     det = model.profile_detail()
     conv_bytes = float(det[:, 9].sum()) if len(det) else 0.0
     if a.detail and rank == 0:
@@ -620,7 +632,8 @@ def main():
     # ---- secondary: the opt-in reduced-precision mode (BASELINE configs[2] says "bf16"; the reference's model_fp16 /
     # quantised variants, hf_cache.rs:135-144).  Never `value`: narrower than the reference's fp32 default. ----
     reduced = None
-    if a.reduced and rank == 0 and world == 1 and conv_mode == 1:
+    f32_class = None
+    if a.reduced and rank == 0 and world == 1 and conv_mode in (1, 6):
         model.set_pinned_durations([3, 3, 3, 4])
         model.set_utterance_base(rank * B)
 
@@ -638,7 +651,7 @@ def main():
                 n3, ms3, fl3 = model.profile_read()
                 model.profile_enable(False)
             finally:
-                model.set_conv_mode(1)
+                model.set_conv_mode(conv_mode)
             # (the family mixes launches at one MFMA per product -- the decoder / generator direct-A convs -- with launches
             # at three: `achieved` is algorithmic FLOPs over time, the issue factor is stated, no pipe utilisation is derived)
             ach3 = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
@@ -648,6 +661,13 @@ def main():
                                  "frac": ach3 / PEAK_F16_MFMA_TFLOPS, "mfma_issue_factor": "1 on the direct-A convs, 3 elsewhere",
                                  "avg_launch_ms": ms3 / max(n3, 1), "launches_per_step": n3 / max(a.steps, 1)}}
 
+        if conv_mode == 6:
+            # the same steps with three f16 MFMAs per product everywhere (KOKOROX_CONV=f16x3, the default of rounds 2-4): what the
+            # 8-bit cross terms buy, and the figure to compare with earlier rounds
+            f32_class = reduced_run(1, "f16x3")
+            f32_class["roofline"]["mfma_issue_factor"] = 3
+            f32_class["mode"] = ("KOKOROX_CONV=f16x3: every product as three f16 MFMAs on hi / lo halves (~22 significant bits); the "
+                                 "default mode's waveform differs from it by < 1e-5")
         reduced = reduced_run(4, "f16")
         reduced["mode"] = ("KOKOROX_CONV=f16: one v_mfma_f32_32x32x16_f16 per product in the decoder / generator convs of the "
                            "direct-A kernel (f16 operands, f32 accumulate); duration head, F0/N predictor, source, STFT f32-class")
@@ -731,7 +751,7 @@ def main():
             "finite": finite,
             "weight_broadcast_s": t_bcast,
             "model_tflops": flops_per_utt * world * B * a.steps / wall / 1e12,
-            "roofline": roofline(f16x3, conv_flops, conv_ms, n_launch, a.steps, wall, B, T, F, conv_bytes),
+            "roofline": roofline(f16x3, conv_flops, conv_ms, n_launch, a.steps, wall, B, T, F, conv_bytes, f8=conv_mode == 6),
             # unfused InstanceNorm statistics passes of the timed steps: each reads its tensor once (the known byte
             # count tools/summarize_pmc.py checks FETCH_SIZE against)
             "in_stats": {"launches_per_step": stats_launches / max(a.steps, 1), "bytes_per_step": stats_bytes / max(a.steps, 1)},
@@ -739,6 +759,7 @@ def main():
             "latency_b1": lat_b1,
             "pcie_inclusive": pcie,
             "reduced_precision": reduced,
+            "f16x3_mode": f32_class,
         }
         out["serve"] = None
         if world == 1 and a.serve:

@@ -451,9 +451,9 @@ static void launch_inst16(const ConvArgs& a, int B, int max_cols, hipStream_t s)
 // launch geometry (an utterance's sums are added in the same order alone and beside a longer one: batch invariance), so the
 // 2 x 2-wave tile of short sequences (64-column slots) is not taken.
 void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int stride, int* bn, int* wn, int ws_force, bool stats,
-                      int act, int n_chunks16, bool prec1) {
+                      int act, int n_chunks16, int pmode) {
     static const int force = env_int("KX_BN", 0);
-    if (ws_force != 1 && act >= 0 && conv16_da_s16_shape(BM, K, dil, stride, act, n_chunks16, false, prec1)) {
+    if (ws_force != 1 && act >= 0 && conv16_da_s16_shape(BM, K, dil, stride, act, n_chunks16, false, pmode)) {
         // the S16 form of the direct-A conv: 192 columns on chip-filling grids, 128 on small ones; three / two 64-column slots
         const bool small = (long)((max_cols + 255) / 256) * ((Cout + 127) / 128) * B < 256 && ws_force != 2;
         *bn = small ? 128 : 192;
@@ -483,8 +483,8 @@ int conv16_flat_bn(const ConvArgs& a, int BM, int B, int max_cols) {
     if (a.K == 1 && a.stride == 1 && !a.stat_part && !a.in_up2 && a.n_chunks16 >= 3 && a.act != ACT_SNAKE) return 0;  // k = 1 GEMM forms
     int bn, wn;
     conv16_pick_tile(BM, max_cols, B, a.Cout, a.K, a.dil, a.stride, &bn, &wn, a.ws_force, a.stat_part != nullptr, a.act, a.n_chunks16,
-                     a.prec1 != 0);
-    if (conv16_da_s16_shape(BM, a.K, a.dil, a.stride, a.act, a.n_chunks16, a.merge_T > 0, a.prec1 != 0)) return bn;  // 192 / 128
+                     conv16_pmode(a));
+    if (conv16_da_s16_shape(BM, a.K, a.dil, a.stride, a.act, a.n_chunks16, a.merge_T > 0, conv16_pmode(a))) return bn;  // 192 / 128
     if (bn == 128 && wn == 1) return conv16_use_da(BM, a.K, a.dil, a.stride, a.merge_T > 0) ? 128 : 0;
     if (bn == 128) return 0;
     return conv16_use_da(BM, a.K, a.dil, a.stride, a.merge_T > 0) ? 256 : 0;
@@ -532,8 +532,8 @@ void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStre
         KX_REQUIRE(a.epi != EPI_GELU_NEW, "conv1d f16x3: gelu epilogue exists only for k=1 GEMMs with >= 48 input channels");
         int bn, wn;
         conv16_pick_tile(BM, max_cols, B, a.Cout, a.K, a.dil, a.stride, &bn, &wn, a.ws_force, a.stat_part != nullptr, a.act, a.n_chunks16,
-                         a.prec1 != 0);
-        if (a.ws_force != 1 && conv16_da_s16_shape(BM, a.K, a.dil, a.stride, a.act, a.n_chunks16, a.merge_T > 0, a.prec1 != 0))
+                         conv16_pmode(a));
+        if (a.ws_force != 1 && conv16_da_s16_shape(BM, a.K, a.dil, a.stride, a.act, a.n_chunks16, a.merge_T > 0, conv16_pmode(a)))
             launch_conv1d_f16x3_da(a, B, max_cols, s, bn);  // (bn = 192 or 128: the S16 form's tiles)
         else if (bn == 128 && wn == 1 && conv16_use_da(BM, a.K, a.dil, a.stride, a.merge_T > 0) && a.ws_force != 1)
             launch_conv1d_f16x3_da(a, B, max_cols, s, 128);  // (test hook mode 2 keeps the LDS-DMA form for comparison)
@@ -689,8 +689,8 @@ __global__ void pack_conv8x_kernel(const _Float16* w16, unsigned* dst, int K, lo
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total_dwords; e += (long)gridDim.x * blockDim.x) {
         long q = e;
         const int d = q % 4; q /= 4;
-        const int sl = q % 2; q /= 2;
         const int row = q % 128; q /= 128;
+        const int sl = q % 2; q /= 2;
         const int g = q % 4; q /= 4;
         const int mg = q % NG; q /= NG;  // q: row tile x chunk
         const int tap = 4 * mg + 2 * (g >> 1) + sl, hh = g & 1;

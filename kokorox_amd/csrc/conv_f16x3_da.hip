@@ -41,6 +41,10 @@
 #include <type_traits>
 
 
+#ifndef KX_F8_HWCOS
+#define KX_F8_HWCOS 1  // f16f8 forms: the snake's sin^2 on v_cos_f32 (0: the polynomial of the other forms)
+#endif
+
 namespace kx {
 
 // compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N - 1 (indices that must be constants BEFORE any loop
@@ -179,6 +183,16 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
             split_pair(v0, v1, hi_pk, lo_pk);
         }
     };
+    // the input activation of the staging paths: in_act, or (f16f8 snake) the hardware-cosine form of xform_a / _b / _c below, operation
+    // for operation (a chunk's values must not depend on which path transformed it)
+    auto act_in = [](float y, float slope, float al, float ial) __attribute__((always_inline)) {
+        if constexpr (ACT == ACT_SNAKE && F8 && KX_F8_HWCOS) {
+            const float u = (al * y) * 0.318309886183790672f;
+            return __builtin_fmaf(ial, __builtin_fmaf(-0.5f, __builtin_amdgcn_cosf(u), 0.5f), y);
+        } else {
+            return in_act<ACT>(y, slope, al, ial);
+        }
+    };
     using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
     // the high-half product of a P1 form: f16 or bf16 operands
     auto mfma_hi = [](const half8& ah, const half8& bh, const f32x16& c) __attribute__((always_inline)) {
@@ -299,6 +313,7 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
     unsigned okq = 0;
     const buf_rsrc xq = make_buf(PRE ? reinterpret_cast<const char*>(a.x16) + (long)b * a.x16_bs : reinterpret_cast<const char*>(a.x));
     const unsigned chunk_bytes = PRE ? 64u * (unsigned)a.x16_ld : 0u;  // four planes of x16_ld columns x 16 B
+    const buf_rsrc xrow = make_buf(xb);  // (f16f8 forms: the utterance's rows; an utterance's tensor is < 4 GiB, checked at launch)
     if constexpr (PRE) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -337,6 +352,27 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
             return;
         }
         load_params(ch, praw);
+        if constexpr (F8) {
+            // f16f8 forms: buffer loads -- the utterance's descriptor in scalar registers, the lane's column as a 32-bit offset, the
+            // channel's row as a scalar offset: no 64-bit vector address per load and no address registers (the 192-column tile has
+            // none to spare)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int ci = ch * CK16 + g * 8 + c;
+                const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(ci < cmax_in ? ci : cmax_in) * (4u * (unsigned)a.x_ld);
+#pragma unroll
+                for (int j = 0; j < NJF; ++j) raw[j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrow, 4u * (unsigned)xoff[j], so, 0));
+            }
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int ci = ch * CK16 + g * 8 + jb * 4 + c;
+                    const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(ci < cmax_in ? ci : cmax_in) * (4u * (unsigned)a.x_ld);
+                    raw[NJF][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrow, 4u * (unsigned)xoff[NJF], so, 0));
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int ci = ch * CK16 + g * 8 + c;
@@ -373,7 +409,7 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int c = 2 * c2 + q;
-                const float y = in_act<ACT>(__builtin_fmaf(x8[c] - o.m[c], o.s[c], o.h[c]), a.slope, o.al[c], o.ial[c]);  // (explicit fma: see conv_epilogue.h)
+                const float y = act_in(__builtin_fmaf(x8[c] - o.m[c], o.s[c], o.h[c]), a.slope, o.al[c], o.ial[c]);  // (explicit fma: see conv_epilogue.h)
                 y2[q] = y * keep;
             }
             pack_pair(y2[0], y2[1], hp[c2], lp[c2]);
@@ -397,7 +433,7 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
                 const float sh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv[2]), cl));
                 const float al = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al_or_rcp), cl));
                 const float ial = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al_or_rcp), cl + 8));
-                const float y = in_act<ACT>(__builtin_fmaf(x8[c] - m, sc, sh), a.slope, al, ial);
+                const float y = act_in(__builtin_fmaf(x8[c] - m, sc, sh), a.slope, al, ial);
                 y2[q] = y * keep;
             }
             pack_pair(y2[0], y2[1], hp[c2], lp[c2]);
@@ -461,7 +497,12 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
         // (an opaque hand-over: two half-units on one tile otherwise get SLP-packed into v_pk_add_f32 / v_pk_fma_f32, which
         // are slow beside MFMAs on gfx950 -- seen in the generated code of the leaky k = 3 form)
         asm volatile("" : "+v"(xt_));
-        if (ACT == ACT_SNAKE) {
+        if (ACT == ACT_SNAKE && F8 && KX_F8_HWCOS) {
+            // f16f8: sin^2 t = 0.5 - 0.5 cos 2t on the hardware cosine (v_cos_f32 takes turns: 2t / 2 pi), max error 3.1e-6 absolute
+            // (tools/probes/sin_accuracy.hip) -- under this mode's 1e-5 per product -- for 5 vector-issue slots instead of 12
+            const float al = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al_rcp_x), cq));
+            xz_ = (al * xt_) * 0.318309886183790672f;
+        } else if (ACT == ACT_SNAKE) {
             const float al = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al_rcp_x), cq));
             const float t = al * xt_;
             const float n = rintf(t * 0.318309886183790672f);
@@ -471,7 +512,9 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
         }
     };
     auto xform_b = [&]() __attribute__((always_inline)) {
-        if (ACT == ACT_SNAKE) {
+        if (ACT == ACT_SNAKE && F8 && KX_F8_HWCOS) {
+            xz_ = __builtin_fmaf(-0.5f, __builtin_amdgcn_cosf(xz_), 0.5f);
+        } else if (ACT == ACT_SNAKE) {
             const float z = xz_;
             float pp = fmaf(z, -3.6197402550897095e-06f, 1.3928599946666651e-04f);
             pp = fmaf(z, pp, -3.1722760759294033e-03f);
@@ -665,18 +708,33 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
         int d_xl = tau16 ? 0 : dil;      // its second slot in a chunk's LAST group: the next tap, or (padding) the same one again
         using v8i = __attribute__((ext_vector_type(8))) int;
         u32x4 hs[RH][2], xs[RC][4];
-        const uint4* wxlane = reinterpret_cast<const uint4*>(a.w8x) + (long)ct * n_chunks * NG * 1024 + ((lane >> 4) * 128 + wave * 32 + r16) * 2;
+        // The ring loads are buffer loads: the image's descriptor in scalar registers, a per-lane byte offset that never changes
+        // and a scalar offset per load -- no 64-bit vector address arithmetic and no address registers (the 192-column tile has
+        // none to spare: with global loads it spilled, and a spill reload is a vector-memory operation that drains the ring).
+        auto make_srd = [](const void* base) __attribute__((always_inline)) {
+            const unsigned long long pa = (unsigned long long)base;
+            u32x4 srd;
+            srd[0] = __builtin_amdgcn_readfirstlane((unsigned)pa);
+            srd[1] = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32) & 0xffffu);
+            srd[2] = 0xffffffffu;
+            srd[3] = 0x00020000u;  // (raw buffer, as make_buf)
+            return srd;
+        };
+        const u32x4 srd_h = make_srd(a.w16), srd_x = make_srd(a.w8x);
+        const unsigned voff_h = 16u * (unsigned)(tau16 * tap_units + h16 * BM + wave * 32 + r16);
+        const unsigned voff_x = 16u * (unsigned)((lane >> 4) * 256 + wave * 32 + r16);  // [g][slot][row][16 B]
+        const unsigned tile_h = (unsigned)__builtin_amdgcn_readfirstlane(ct * n_steps), tile_x8 = (unsigned)__builtin_amdgcn_readfirstlane(ct * n_chunks * NG);
         auto load_H = [&](int s0, u32x4 (&xh)[2]) __attribute__((always_inline)) {
-            const uint4* pp = wlane16 + (long)(s0 < n_steps - 2 ? s0 : n_steps - 2) * tap_units;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xh[0]) : "v"(pp) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off offset:256" : "=v"(xh[1]) : "v"(pp) : "memory");
+            const unsigned so = (tile_h + (unsigned)__builtin_amdgcn_readfirstlane(s0 < n_steps - 2 ? s0 : n_steps - 2)) * (16u * tap_units);
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(xh[0]) : "v"(voff_h), "s"(srd_h), "s"(so) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:256" : "=v"(xh[1]) : "v"(voff_h), "s"(srd_h), "s"(so) : "memory");
         };
         auto load_X = [&](int chunk, const int m, u32x4 (&x)[4]) __attribute__((always_inline)) {
-            const uint4* pp = wxlane + ((long)(chunk < n_chunks ? chunk : n_chunks - 1) * NG + m) * 1024;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x[0]) : "v"(pp) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(x[1]) : "v"(pp) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(x[2]) : "v"(pp) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off offset:528" : "=v"(x[3]) : "v"(pp) : "memory");
+            const unsigned so = (tile_x8 + (unsigned)__builtin_amdgcn_readfirstlane(chunk < n_chunks ? chunk : n_chunks - 1) * NG + m) * 16384u;
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(x[0]) : "v"(voff_x), "s"(srd_x), "s"(so) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:2048" : "=v"(x[1]) : "v"(voff_x), "s"(srd_x), "s"(so) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:256" : "=v"(x[2]) : "v"(voff_x), "s"(srd_x), "s"(so) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:2304" : "=v"(x[3]) : "v"(voff_x), "s"(srd_x), "s"(so) : "memory");
         };
         static_for<0, RH>([&](auto qc) __attribute__((always_inline)) { load_H(2 * decltype(qc)::value, hs[decltype(qc)::value]); });
         static_for<0, RC>([&](auto qc) __attribute__((always_inline)) {
@@ -744,7 +802,11 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
                     if constexpr (FS::cross_of(ip / NB) >= 0) load_blk_x(FS::cross_of(ip / NB), ip % NB, fx[e ^ 1]);
                 }
                 if constexpr (i % G == 0) __builtin_amdgcn_sched_barrier(0);
+#ifdef KX_F8_NO_CROSS  // (diagnostic build: the cross-term MFMAs dropped, results wrong: timing only)
+                if constexpr (false) {
+#else
                 if constexpr (c >= 0) {
+#endif
                     const v8i x0 = v8i{(int)xs[xsl][0][0], (int)xs[xsl][0][1], (int)xs[xsl][0][2], (int)xs[xsl][0][3],
                                        (int)xs[xsl][1][0], (int)xs[xsl][1][1], (int)xs[xsl][1][2], (int)xs[xsl][1][3]};
                     const v8i x1 = v8i{(int)xs[xsl][2][0], (int)xs[xsl][2][1], (int)xs[xsl][2][2], (int)xs[xsl][2][3],
@@ -763,6 +825,11 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
                 constexpr int h1 = (inA || inB) ? FS::hu_before(NB, NA, HU, first, I0, rel + 1) : 0;
                 static_assert(h1 - h0 <= 2, "at most two half-units per block");
                 uint4* Xdst = Xs + (inA ? 1 : 0) * XBUF;
+#ifdef KX_DA_NO_XFORM  // (diagnostic build: the transform's vector work and LDS writes dropped, image stale: timing only)
+                if constexpr (h1 > h0) keep_elem(h0);
+                if constexpr (h1 > h0 + 1) keep_elem(h0 + 1);
+                (void)Xdst;
+#else
                 if constexpr (h1 > h0) {
                     xform_a(h0 / 2, h0 & 1, 0);
                     xform_b();
@@ -773,6 +840,7 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
                     xform_b();
                     xform_c((h0 + 1) / 2, (h0 + 1) & 1, Xdst, 0);
                 }
+#endif
                 if constexpr (i % G == G - 1) {  // the pipeline of the region: its half-units spread over its MFMAs by their duration
                     constexpr int ig = i - (G - 1);
                     constexpr bool gA = ig < NA, gB = ig >= SB0;
@@ -780,7 +848,7 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
                     constexpr int hg0 = (gA || gB) ? FS::hu_before(NB, NA, HU, gfirst, gI0, grel) : 0;
                     constexpr int nh = h1 > hg0 ? h1 - hg0 : 0;
                     constexpr int units = G * (c >= 0 ? 6 : 2);  // (16-cycle units: a scaled MFMA is two)
-                    constexpr int per = nh > 0 ? (nh * (UVI + 7) + units - 1) / units : 0;
+                    constexpr int per = nh > 0 ? (nh * (UVI + (KX_F8_HWCOS ? 0 : 7)) + units - 1) / units : 0;
 #pragma unroll
                     for (int tg = 0; tg < G; ++tg) {
                         if (tg > 0) __builtin_amdgcn_sched_group_barrier(0x100, c >= 0 ? 3 : 1, 0);
@@ -1470,6 +1538,7 @@ void launch_conv1d_f16x3_da_f8(const ConvArgs& a, int B, int max_cols, hipStream
                    a.n_chunks16 >= 2 && (a.n_chunks16 & 1) == 0,
                "conv1d f16x3 da f8: launch not eligible");
     KX_REQUIRE(bn == 192 || bn == 128, "conv1d f16x3 da f8: tile of 192 or 128 columns");
+    KX_REQUIRE((long)a.Cin * a.x_ld * 4 < (1L << 32), "conv1d f16x3 da f8: input tensor of one utterance beyond 4 GiB");
     if (a.K == 11) {
         if (bn == 192) launch_da_inst<ACT_SNAKE, 11, 6>(a, B, max_cols, s);
         else launch_da_inst<ACT_SNAKE, 11, 4>(a, B, max_cols, s);
@@ -1482,19 +1551,21 @@ void launch_conv1d_f16x3_da_f8(const ConvArgs& a, int B, int max_cols, hipStream
 // The S16 forms (conv_f16x3_da_s16.hip defines KX_DA_S16 and includes this file).
 // Shapes the S16 form takes (and conv16_pick_tile gives 64-column statistics slots): snake resblock convs with 11 taps and an even
 // number of 16-channel chunks, and (round 4) the un-dilated 7-tap ones.  KX_DA_S16=0 switches the form off, 2 keeps it to 11 taps.
-bool conv16_da_s16_shape(int BM, int K, int dil, int stride, int act, int n_chunks16, bool merged, bool prec1) {
+bool conv16_da_s16_shape(int BM, int K, int dil, int stride, int act, int n_chunks16, bool merged, int pmode) {
     static const int on = getenv("KX_DA_S16") ? atoi(getenv("KX_DA_S16")) : 1;
     static const int da = getenv("KX_DA") ? atoi(getenv("KX_DA")) : 1;
     static const int st = getenv("KX_DA_STATIC") ? atoi(getenv("KX_DA_STATIC")) : 1;
     // 11 taps: always.  7 taps: the un-dilated launches only (measured: the big 7-tap launches gain 3 % on this form, the
     // dilated ones lose 3 %: profiles/r03_s16_form.txt; KX_DA_S16=2 keeps the 7-tap convs off it).  The choice depends on the
     // layer's shape alone, never on the batch, so an utterance's bits do not depend on what it is batched with.
-    const bool taps = K == 11 || (K == 7 && dil == 1 && on == 1);
-    return on && da && st && BM == 128 && stride == 1 && !merged && !prec1 && act == ACT_SNAKE && taps && (K - 1) * dil <= 64 &&
+    // pmode: 0 = f16x3, 1 = a reduced-precision launch (never this form), 2 = f16f8 (the layer carries an 8-bit cross image: every
+    // 7-tap conv takes the form -- with two MFMA-equivalents per product the dilated ones gain 18 % on it instead of losing 3 %)
+    const bool taps = K == 11 || (K == 7 && dil == 1 && on == 1) || (K == 7 && pmode == 2);
+    return on && da && st && BM == 128 && stride == 1 && !merged && pmode != 1 && act == ACT_SNAKE && taps && (K - 1) * dil <= 64 &&
            n_chunks16 >= 2 && (n_chunks16 & 1) == 0;
 }
 void launch_conv1d_f16x3_da_s16(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn) {
-    KX_REQUIRE(conv16_da_s16_shape(128, a.K, a.dil, a.stride, a.act, a.n_chunks16, a.merge_T > 0, a.prec1 != 0), "conv1d f16x3 da s16: launch not eligible");
+    KX_REQUIRE(conv16_da_s16_shape(128, a.K, a.dil, a.stride, a.act, a.n_chunks16, a.merge_T > 0, conv16_pmode(a)), "conv1d f16x3 da s16: launch not eligible");
     KX_REQUIRE(bn == 192 || bn == 128, "conv1d f16x3 da s16: tile of 192 or 128 columns");
     if (a.K == 11) {
         if (bn == 192) launch_da_inst<ACT_SNAKE, 11, 6>(a, B, max_cols, s);
@@ -1594,7 +1665,7 @@ void launch_conv1d_f16x3_da(const ConvArgs& a, int B, int max_cols, hipStream_t 
     }
     // 7 / 11-tap snake convs: the 16x16x32 form on its 192- or 128-column tile (conv16_pick_tile chose bn and the 64-column
     // statistics slots for it by the same predicate)
-    if (conv16_da_s16_shape(128, a.K, a.dil, a.stride, a.act, a.n_chunks16, a.merge_T > 0, a.prec1 != 0)) {
+    if (conv16_da_s16_shape(128, a.K, a.dil, a.stride, a.act, a.n_chunks16, a.merge_T > 0, conv16_pmode(a))) {
         if (a.w8x && conv16_da_f8_shape(a.K, a.dil)) launch_conv1d_f16x3_da_f8(a, B, max_cols, s, bn == 128 ? 128 : 192);  // (CONV_F16F8)
         else launch_conv1d_f16x3_da_s16(a, B, max_cols, s, bn == 128 ? 128 : 192);
         return;

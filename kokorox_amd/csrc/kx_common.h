@@ -176,9 +176,12 @@ size_t packed_conv_floats(int rows, int Cin, int K, int BM);
 // f16x3 split path
 enum ConvMode { CONV_F32 = 0, CONV_F16X3 = 1, CONV_F16X3_LDS = 2, CONV_F16X3_DA = 3, CONV_F16 = 4, CONV_BF16 = 5, CONV_F16F8 = 6 };  // (2, 3: test hook only: f16x3 kept on the LDS-DMA kernel forms of conv_f16x3.hip / forced through conv_f16x3_da.hip)
 void launch_conv1d_f16x3(const ConvArgs& a, int BM, int B, int max_cols, hipStream_t s);
-// (act / n_chunks16 / prec1: given, the shapes of the direct-A S16 form get its tiles: 192 or 128 columns, 64-column statistics slots)
+// precision class of a launch, as the shape rules see it: 0 = f16x3, 1 = reduced precision (one MFMA per product), 2 = f16f8 (the
+// layer carries an 8-bit cross image)
+inline int conv16_pmode(const ConvArgs& a) { return a.prec1 ? 1 : (a.w8x ? 2 : 0); }
+// (act / n_chunks16 / pmode: given, the shapes of the direct-A S16 form get its tiles: 192 or 128 columns, 64-column statistics slots)
 void conv16_pick_tile(int BM, int max_cols, int B, int Cout, int K, int dil, int stride, int* bn, int* wn,
-                      int ws_force = 0, bool stats = false, int act = -1, int n_chunks16 = 0, bool prec1 = false);  // (conv_f16x3.hip)
+                      int ws_force = 0, bool stats = false, int act = -1, int n_chunks16 = 0, int pmode = 0);  // (conv_f16x3.hip)
 // conv_f16x3_da.hip: the 128 x 256 tile with the weight fragments loaded from global memory straight into registers
 bool conv16_use_da(int BM, int K, int dil, int stride, int merged);       // eligible AND switched on (default; KX_DA=0 turns it off)
 bool conv16_da_eligible(int BM, int K, int dil, int stride, int merged);  // shape fits the kernel
@@ -190,7 +193,7 @@ void launch_conv1d_f16x3_dag(const ConvArgs& a, int B, int max_cols, hipStream_t
 int conv16_cu_count();  // CUs of the current device, or of the launching model's CU partition (conv_f16x3.hip)
 int cu_count_override(); // model.hip: the CU partition of the model that is launching on this thread (0 = none)
 // shapes that take the 16x16x32 form of the direct-A conv (conv_f16x3_da_s16.hip): 192 / 128-column tiles, 64-column statistics slots
-bool conv16_da_s16_shape(int BM, int K, int dil, int stride, int act, int n_chunks16, bool merged, bool prec1);
+bool conv16_da_s16_shape(int BM, int K, int dil, int stride, int act, int n_chunks16, bool merged, int pmode);
 size_t packed_conv16_halves(int rows, int Cin, int K, int BM);
 float device_absmax(const float* p, long n, hipStream_t s);
 int pick_weight_shift(float absmax);
@@ -200,8 +203,9 @@ void launch_pack_convT16(const float* w, void* dst, int Cin, int Cout, int sd, i
 void launch_image_to_bf16(const void* w16, void* dst, size_t n_halves, hipStream_t s);
 // f16f8 mode: the cross terms a_lo b_hi + a_hi b_lo of the split product on v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 x e4m3, twice the
 // f16 rate), a_hi b_hi stays on the f16 MFMA.  The weights' side of the cross terms, from a split-f16 image of 128-row tiles:
-// [row tile][chunk16][tap group of 4][k-group g = octet + 2 (tap pair)][128 rows][32 B], the 32 B = two slots of 16 B (taps
-// 4 m + 2 (g >> 1) and + 1; taps >= K are zero), a slot = four dwords [e4m3(2^7 lo(2d)), e4m3(2^7 lo(2d+1)), e4m3(2^-4 hi(2d)),
+// [row tile][chunk16][tap group of 4][k-group g = octet + 2 (tap pair)][slot 0 | 1][128 rows][16 B] (a lane's 32-byte operand is
+// its row's two slots: taps 4 m + 2 (g >> 1) and + 1; taps >= K are zero; a load instruction reads one slot of 16 consecutive
+// rows = 256 contiguous bytes), a slot = four dwords [e4m3(2^7 lo(2d)), e4m3(2^7 lo(2d+1)), e4m3(2^-4 hi(2d)),
 // e4m3(2^-4 hi(2d+1))] of the octet's channel pairs d -- byte for byte the partner of the activation image's 8-bit plane
 // (split_pair_f8, conv_f16x3_common.h); the products of a slot carry 2^7 (undone by the instruction's block scale).
 size_t packed_conv8x_bytes(int rows, int Cin, int K);

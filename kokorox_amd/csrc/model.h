@@ -178,7 +178,7 @@ class Model {
     uint64_t utt_base = 0;
     void set_lanes(int n) { lanes_cfg_ = n < 0 ? 0 : (n > N_LANES ? N_LANES : n); }
     void set_conv_mode(int mode);  // (modes 5 / 6 build the bf16 / 8-bit cross weight images on first use)
-    int conv_mode = CONV_F16X3;
+    int conv_mode = CONV_F16F8;  // (default since round 5; KOKOROX_CONV=f16x3 / kx_set_conv_mode(1): three f16 MFMAs per product everywhere)
     int stft_variant = STFT_ONNX;  // the ONNX export's conv-based STFT pair (what the reference runs)
     int device;
 

@@ -654,8 +654,7 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
         const int max_c = out.Lmax;
         int bn, wn;
         if (f16) {
-            conv16_pick_tile(w.BM, max_c, B_, w.rows, w.K, o.dil, o.stride, &bn, &wn, 0, true, o.act, w.n_chunks16,
-                             (conv_mode == CONV_F16 || conv_mode == CONV_BF16) && p1_region_);
+            conv16_pick_tile(w.BM, max_c, B_, w.rows, w.K, o.dil, o.stride, &bn, &wn, 0, true, o.act, w.n_chunks16, conv16_pmode(a));
         } else {
             bn = conv_bn(w.BM);
             wn = w.BM == 128 ? 2 : 4;

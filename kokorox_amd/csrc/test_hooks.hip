@@ -207,7 +207,7 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
             KX_REQUIRE(!transposed && !ex.accum, "test_conv1d: fused statistics come with plain, non-accumulating stores");
             int bn, wn;
             if (mode != kx::CONV_F32) {
-                kx::conv16_pick_tile(BM, Lout, B, rows, a.K, a.dil, a.stride, &bn, &wn, a.ws_force, true, a.act, (Cin + 15) / 16, false);
+                kx::conv16_pick_tile(BM, Lout, B, rows, a.K, a.dil, a.stride, &bn, &wn, a.ws_force, true, a.act, (Cin + 15) / 16, f8 ? 2 : 0);
             } else {
                 bn = kx::conv_bn(BM);
                 wn = BM == 128 ? 2 : 4;

@@ -408,7 +408,8 @@ class HipKoko:
         return list(out)
 
     def set_conv_mode(self, mode: int):
-        """0 = f32 MFMA, 1 = f16x3 split MFMA (default), 4 = f16 single product (opt-in reduced precision)."""
+        """0 = f32 MFMA, 1 = f16x3 split MFMA, 6 = f16f8 (default: f16x3 with the cross terms of the 7 / 11-tap convs on 8-bit
+        MFMAs), 4 / 5 = f16 / bf16 single product (opt-in reduced precision)."""
         self._check(self._lib.kx_set_conv_mode(self._h, mode))
 
     def get_conv_mode(self) -> int:
@@ -607,7 +608,7 @@ def _err_call(fn, *args):
         raise KokoroxHipError(rc, err.value.decode())
 
 
-CONV_F32, CONV_F16X3 = 0, 1
+CONV_F32, CONV_F16X3, CONV_F16F8 = 0, 1, 6
 STFT_ONNX, STFT_TORCH = 0, 1
 
 

@@ -20,7 +20,8 @@ HIPCC = "/opt/rocm/bin/hipcc"
 # every translation unit this file audits, with its extra flags: compiled to assembly side by side on first use (five hipcc runs
 # of 10 - 70 s each; in a row they were most of the CPU suite's time)
 _UNITS = {"conv_f16x3_da.hip": ("-DKX_DA_AUDIT",), "conv_f16x3_da_p1.hip": ("-DKX_DA_AUDIT",), "conv_f16x3_da_w2.hip": ("-DKX_DA_AUDIT",),
-          "conv_f16x3_da_s16.hip": ("-DKX_DA_AUDIT",), "conv_f16x3_dag.hip": (), "conv_f16x3_da_pre.hip": (), "conv_f16x3_dapn.hip": ()}
+          "conv_f16x3_da_s16.hip": ("-DKX_DA_AUDIT",), "conv_f16x3_dag.hip": (), "conv_f16x3_da_pre.hip": (), "conv_f16x3_dapn.hip": (),
+          "conv_f16x3_da_f8.hip": ()}
 _ASM_JOBS = {}
 
 
@@ -38,7 +39,7 @@ def _asm(src, tmp_path, *flags):
         import tempfile
         from concurrent.futures import ThreadPoolExecutor
         out_dir = tempfile.mkdtemp(prefix="kx_asm_audit_")
-        ex = ThreadPoolExecutor(max_workers=min(7, os.cpu_count() or 1))
+        ex = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1))
         for u, fl in _UNITS.items():
             _ASM_JOBS[u] = ex.submit(_asm_one, u, fl, out_dir)
         ex.shutdown(wait=False)
@@ -94,7 +95,7 @@ def _audit_no_touch_before_wait(lines):
             continue
         if re.match(r"(global|buffer|flat|scratch)_(load|store|atomic)", s):
             vm += 1
-            if in_asm and s.startswith("global_load_dword") and toks:  # ring (dwordx4) and input prefetch (dword) loads
+            if in_asm and (s.startswith("global_load_dword") or s.startswith("buffer_load_dwordx4")) and toks:  # ring (dwordx4) and input prefetch (dword) loads
                 pending.append((_regs(toks[0]), vm))
                 continue
         if in_asm:
@@ -161,6 +162,103 @@ def test_direct_a_conv_assembly(tmp_path, src):
             valu = sum(1 for ln in body if re.match(r"\s*v_(?!mfma)", ln))
             budget = {11: 3.0, 7: 4.5, 3: 9.5}[kt]
             assert valu / len(mf) <= budget, f"{name}: {valu / len(mf):.2f} vector instructions per MFMA in the main loop (budget {budget})"
+
+
+def _f8_ages(kt, rh, rc, raw):
+    """F8Sched::age of conv_f16x3_da.hip restated: the wait of every pair-step of a super-chunk in the steady state = vector-memory
+    operations issued since the refill of the slot(s) it hands on (program order: [p == HS: input prefetch] [wait] .. [hi refill: 2]
+    [cross refill: 4]; the input prefetch behind barrier 3)."""
+    hs, ng = (kt - 1) // 2, (kt + 1) // 4
+    nc = 2 * ng
+
+    def cross_of(p):
+        if p & 1:
+            return -1
+        if p <= 2 * (ng - 1):
+            return p // 2
+        if p >= kt - 1 - 2 * (ng - 1):
+            return nc - 1 - (kt - 1 - p) // 2
+        return -1
+
+    n, st_h, st_x, waits = 0, {}, {}, []
+    for sc in range(2):
+        for p in range(kt):
+            if p == hs:
+                n += raw
+            if sc == 1:
+                a = n - st_h[kt + p]
+                c = cross_of(p)
+                if c >= 0:
+                    a = min(a, n - st_x[nc + c])
+                waits.append(min(a, 63))
+            n += 2
+            st_h[sc * kt + p + rh if p + rh <= kt - 1 else (sc + 1) * kt + p % rh] = n
+            c = cross_of(p)
+            if c >= 0:
+                n += 4
+                st_x[sc * nc + c + rc] = n
+        n += raw
+    return waits
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_f16f8_conv_assembly(tmp_path):
+    """The f16f8 forms of the 16x16x32 loop (conv_f16x3_da_f8.hip): their rings are buffer loads in inline asm with waits that are
+    compile-time constants (F8Sched::age).  Checked on the generated code: no spill inside the main loop (a spill reload is a vector-
+    memory operation that drains the ring), the input prefetch is raw_ops loads, the waits of a super-chunk are those of an
+    independent restatement of the schedule, no ring register is touched before its wait, and the MFMA mix is 2 f16 per block plus
+    2 scaled per block of a cross-term pair-step."""
+    ks = _kernels(_asm("conv_f16x3_da_f8.hip", tmp_path))
+    assert len(ks) == 4, sorted(ks)
+    for name, lines in ks.items():
+        m = re.search(r"da_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb0ELb0ELb1ELb0ELb0ELb1E", name)
+        assert m, name
+        act, kt, ntt = (int(x) for x in m.groups())
+        assert act == 2 and kt in (7, 11) and ntt in (4, 6)
+        mf = [i for i, ln in enumerate(lines) if "v_mfma" in ln]
+        body = lines[mf[0]:mf[-1] + 1]
+        assert not any("scratch_" in ln for ln in body), f"{name} spills inside the main loop"
+        bad = _audit_no_touch_before_wait(lines)
+        assert not bad, f"{name}: ring registers touched before their wait: {bad[:3]}"
+        hu = 16 if ntt == 6 else 12
+        raw = hu + 4
+        # the input prefetch behind a barrier of the loop body: the forms' raw loads are scalar-dword BUFFER loads (the three
+        # InstanceNorm parameters and alpha: global loads)
+        sizes, i = [], 0
+        while i < len(body):
+            if body[i].strip() == "s_barrier":
+                n, j = 0, i + 1
+                while j < len(body) and "v_mfma" not in body[j] and body[j].strip() != "s_barrier":
+                    n += 1 if re.match(r"\s*(buffer|global)_load_dword\s", body[j]) else 0
+                    j += 1
+                sizes.append(n)
+                i = j
+            else:
+                i += 1
+        sizes = [n for n in sizes if n >= 8]  # (barrier 2 is followed by no prefetch)
+        assert sizes and all(sz == raw for sz in sizes), f"{name}: input prefetch is {sizes} loads, raw_ops assumes {raw}"
+        # the hand-written waits of the loop body, in text order (they sit in asm blocks; the compiler's own are outside them)
+        # (collected over the whole kernel: the first one precedes the first MFMA; the prologue's and the exit's own are vmcnt(0))
+        waits, in_asm = [], False
+        for ln in lines:
+            t = ln.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif t.startswith(";;#ASMEND"):
+                in_asm = False
+            elif in_asm and t.startswith("s_waitcnt vmcnt("):
+                waits.append(int(re.search(r"vmcnt\((\d+)\)", t).group(1)))
+        rh = 3 if (kt - 1) % 3 else 4
+        rc = 1 if ntt == 6 else 2
+        assert [w for w in waits if w > 0] == _f8_ages(kt, rh, rc, raw), (name, waits, _f8_ages(kt, rh, rc, raw))
+        nb, ng = 2 * ntt, (kt + 1) // 4
+        n16 = sum(1 for ln in body if "v_mfma_f32_16x16x32_f16" in ln)
+        n8 = sum(1 for ln in body if "v_mfma_scale_f32_16x16x128_f8f6f4" in ln)
+        assert (n16, n8) == (2 * kt * nb, 2 * 2 * ng * nb), (name, n16, n8)
+        valu = sum(1 for ln in body if re.match(r"\s*v_(?!mfma)", ln))
+        # vector instructions per matrix-pipe slot of 16 cycles (a scaled MFMA is two): the loop is bound by the SIMD's vector issue
+        # as much as by the matrix pipe (DESIGN.md), so this must not quietly grow
+        assert valu / (n16 + 2 * n8) <= {11: 2.0, 7: 3.0}[kt], (name, valu / (n16 + 2 * n8))
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")

@@ -33,6 +33,7 @@ def synthetic_inputs(n_phonemes, seed):
 
 def ab(model, cases):
     worst = {}
+    default_mode = model.get_conv_mode()
     for ids, style in cases:
         taps = {}
         for mode in (0, 1):
@@ -46,7 +47,7 @@ def ab(model, cases):
                 continue
             d = float(np.abs(a - b).max() / max(1.0, float(np.abs(a).max())))
             worst[t] = max(worst.get(t, 0.0), d)
-    model.set_conv_mode(1)
+    model.set_conv_mode(default_mode)
     return worst
 
 
