@@ -135,10 +135,14 @@ struct F8Sched {
     }
 };
 
-template <int ACT, int KT, int NTT, bool P1, bool W2 = false, bool S16 = false, bool PRE = false, bool BF = false, bool F8 = false>
+template <int ACT, int KT, int NTT, bool P1, bool W2 = false, bool S16 = false, bool PRE = false, bool BF = false, bool F8 = false, bool HC = false>
 __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_da_kernel(const ConvArgs a) {
     static_assert(!BF || P1, "BF: a form of the reduced-precision kernels only");
     static_assert(!F8 || (S16 && KT % 4 == 3), "F8: a form of the S16 loop; tap groups of four with one padding slot");
+    // HC: the snake's sin^2 from the hardware cosine, as the F8 forms take it (the 3-tap snake convs of the f16f8 mode: their
+    // products stay f16x3, their transform -- which bounds them -- loses a quarter of its vector instructions)
+    static_assert(!HC || (ACT == ACT_SNAKE && !F8 && !P1 && !PRE), "HC: a snake form of the f16x3 kernels");
+    constexpr bool HWC = (F8 || HC) && KX_F8_HWCOS;
     static_assert(!PRE || (!P1 && !S16 && ACT == ACT_NONE), "PRE: the activation lives in the image; f16x3 forms on 32x32x16 only");
     static_assert(!W2 || (KT >= 3 && (KT & 1) && NTT == 8), "W2: odd compile-time tap counts on the 256-column tile");
     static_assert(!S16 || (KT >= 3 && (KT & 1) && !P1 && !W2), "S16: odd compile-time tap counts, three MFMAs per product, 4 x 1 waves");
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
     // the input activation of the staging paths: in_act, or (f16f8 snake) the hardware-cosine form of xform_a / _b / _c below, operation
     // for operation (a chunk's values must not depend on which path transformed it)
     auto act_in = [](float y, float slope, float al, float ial) __attribute__((always_inline)) {
-        if constexpr (ACT == ACT_SNAKE && F8 && KX_F8_HWCOS) {
+        if constexpr (ACT == ACT_SNAKE && HWC) {
             const float u = (al * y) * 0.318309886183790672f;
             return __builtin_fmaf(ial, __builtin_fmaf(-0.5f, __builtin_amdgcn_cosf(u), 0.5f), y);
         } else {
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
         // (an opaque hand-over: two half-units on one tile otherwise get SLP-packed into v_pk_add_f32 / v_pk_fma_f32, which
         // are slow beside MFMAs on gfx950 -- seen in the generated code of the leaky k = 3 form)
         asm volatile("" : "+v"(xt_));
-        if (ACT == ACT_SNAKE && F8 && KX_F8_HWCOS) {
+        if (ACT == ACT_SNAKE && HWC) {
             // f16f8: sin^2 t = 0.5 - 0.5 cos 2t on the hardware cosine (v_cos_f32 takes turns: 2t / 2 pi), max error 3.1e-6 absolute
             // (tools/probes/sin_accuracy.hip) -- under this mode's 1e-5 per product -- for 5 vector-issue slots instead of 12
             const float al = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al_rcp_x), cq));
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
         }
     };
     auto xform_b = [&]() __attribute__((always_inline)) {
-        if (ACT == ACT_SNAKE && F8 && KX_F8_HWCOS) {
+        if (ACT == ACT_SNAKE && HWC) {
             xz_ = __builtin_fmaf(-0.5f, __builtin_amdgcn_cosf(xz_), 0.5f);
         } else if (ACT == ACT_SNAKE) {
             const float z = xz_;
@@ -1487,9 +1491,9 @@ constexpr bool DA_F8 = true;
 constexpr bool DA_F8 = false;
 #endif
 
-template <int ACT, int KT, int NTT, bool W2X = DA_W2, bool PREX = false, bool BFX = false>
+template <int ACT, int KT, int NTT, bool W2X = DA_W2, bool PREX = false, bool BFX = false, bool HCX = false>
 static void launch_da_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
-    auto kern = conv1d_f16x3_da_kernel<ACT, KT, NTT, DA_P1, W2X, DA_S16, PREX, BFX, DA_F8>;
+    auto kern = conv1d_f16x3_da_kernel<ACT, KT, NTT, DA_P1, W2X, DA_S16, PREX, BFX, DA_F8, HCX>;
     constexpr int BN = 32 * NTT;
     // two input buffers (48 / 32 KiB), and never less than the statistics scratch of the epilogue (4 waves x 8.25 KiB)
     constexpr size_t lds_x = 16 * (size_t)2 * 4 * (BN + 128), lds_scr = 4 * 32 * 33 * sizeof(float2);
@@ -1590,6 +1594,7 @@ void launch_conv1d_f16x3_da_w2(const ConvArgs& a, int B, int max_cols, hipStream
     if (a.act == ACT_LEAKY) launch_da_inst<ACT_LEAKY, 3, 8>(a, B, max_cols, s);
     else if (a.K == 11) launch_da_inst<ACT_SNAKE, 11, 8>(a, B, max_cols, s);
     else if (a.K == 7) launch_da_inst<ACT_SNAKE, 7, 8>(a, B, max_cols, s);
+    else if (a.hwcos) launch_da_inst<ACT_SNAKE, 3, 8, true, false, false, true>(a, B, max_cols, s);  // (f16f8 mode: hardware cosine)
     else launch_da_inst<ACT_SNAKE, 3, 8>(a, B, max_cols, s);
 }
 #else
@@ -1619,6 +1624,9 @@ static void launch_da_ntt(const ConvArgs& a, int B, int max_cols, hipStream_t s)
     if (a.act == ACT_SNAKE) {
         if (st && w64 && a.K == 11) launch_da_inst<ACT_SNAKE, 11, NTT, DA_W2, false, BFX>(a, B, max_cols, s);
         else if (st && w64 && a.K == 7) launch_da_inst<ACT_SNAKE, 7, NTT, DA_W2, false, BFX>(a, B, max_cols, s);
+#ifndef KX_DA_P1
+        else if (st && w64 && a.K == 3 && a.hwcos) launch_da_inst<ACT_SNAKE, 3, NTT, DA_W2, false, false, true>(a, B, max_cols, s);
+#endif
         else if (st && w64 && a.K == 3) launch_da_inst<ACT_SNAKE, 3, NTT, DA_W2, false, BFX>(a, B, max_cols, s);
         else launch_da_inst<ACT_SNAKE, 0, NTT, DA_W2, false, BFX>(a, B, max_cols, s);
     } else if (a.act == ACT_LEAKY) {

@@ -638,6 +638,7 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     a.w16b = w.w16b;
     // f16f8 mode (opt-in): the layers that carry an 8-bit cross image run two MFMA-equivalents per product instead of three
     a.w8x = conv_mode == CONV_F16F8 ? w.w8x : nullptr;
+    a.hwcos = conv_mode == CONV_F16F8 && o.act == ACT_SNAKE && w.K == 3 && w.BM == 128;
     a.n_chunks16 = w.n_chunks16;
     static const int xcd_swz = getenv("KX_XCD_SWIZZLE") ? atoi(getenv("KX_XCD_SWIZZLE")) : 1;
     a.xcd_swizzle = xcd_swz;

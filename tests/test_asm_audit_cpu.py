@@ -138,7 +138,8 @@ def test_direct_a_conv_assembly(tmp_path, src):
     assert ks, "no kernel found"
     # every instantiation launch_da_ntt can select, both tile widths; the four unrolled 256-column forms of the 2 x 2 layout
     # (the reduced-precision unit holds every form twice since round 5: f16 and bf16 operands)
-    assert len(ks) == {"conv_f16x3_da_w2.hip": 4, "conv_f16x3_da_s16.hip": 4, "conv_f16x3_da_p1.hip": 28}.get(src, 14), sorted(ks)
+    # (round 5: + the hardware-cosine forms of the 3-tap snake convs, two tile widths in the main unit, one in the 2 x 2 unit)
+    assert len(ks) == {"conv_f16x3_da_w2.hip": 5, "conv_f16x3_da_s16.hip": 4, "conv_f16x3_da_p1.hip": 28}.get(src, 16), sorted(ks)
     for name, lines in ks.items():
         assert not any("scratch_" in ln for ln in lines), f"{name} spills"
         bad = _audit_no_touch_before_wait(lines)

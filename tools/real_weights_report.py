@@ -7,7 +7,8 @@ products; 1 = f16x3 split) with KX_FLAG_TAPS and prints
   * per tap: max |f16x3 - f32| relative to the tap's magnitude (the A/B DESIGN.md §3 names as the first check), and
   * per conv layer: absmax and rms of its input after the AdaIN affine (kx_diag_*), flagging what the split cannot
     carry: |x| > 6e4 (clamped at 65504) and rms < 1e-3 (low half lost to the f16 subnormal quantum), with the
-    power-of-two pre-scale that brings the layer back to rms ~ 1 (kx_set_act_prescale).
+    power-of-two pre-scale that brings the layer back to rms ~ 1 (kx_set_act_prescale); for the 7- / 11-tap convs, whose cross
+    terms the default f16f8 mode carries on e4m3 images, also the narrower window of those (2^-6 .. 448).
 With --apply the suggested pre-scales are set and the A/B is repeated.  Without a path the seeded synthetic blob is used
 (every layer is then in range: the report is the tool's own smoke test).
 """
@@ -88,6 +89,15 @@ def main():
             e = int(np.round(-np.log2(rms)))
             note = f"rms < 1e-3: low halves lost; suggest kx_set_act_prescale(\"{name}\", {e})"
             suggest[name] = e
+        elif k in (7, 11) and 0 < rms * 2.0 ** sh < 2.0 ** -5:
+            # the default mode's 7- / 11-tap convs carry their cross terms on e4m3 images (normal range 2^-6 .. 448): below it the
+            # images lose bits and a product keeps less than the mode's 2^-17 (never less than one f16 MFMA's 2^-12)
+            e = int(np.round(-np.log2(rms)))
+            note = f"f16f8: rms below e4m3's normal range; suggest kx_set_act_prescale(\"{name}\", {e})"
+            suggest[name] = e
+        elif k in (7, 11) and amax * 2.0 ** sh > 448.0:
+            note = ("f16f8: |x| > 448: the cross terms of those elements are clamped (their products keep 2^-12, the rest 2^-17); "
+                    "KOKOROX_CONV=f16x3 carries them fully")
         print(f"  {name:58s} {rows:5d} {cin:5d} {k:3d} {amax:10.3e} {rms:10.3e}  {note}")
     if not suggest:
         print("every layer is inside the range the split carries exactly (1e-3 <= rms, absmax <= 6e4)")
