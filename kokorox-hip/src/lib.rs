@@ -391,6 +391,8 @@ impl HipKoko {
         self.check(unsafe { kx_arena_bytes(self.h, v.as_mut_ptr()) })?;
         Ok(v)
     }
+    /// Contraction arithmetic: 6 = f16f8 (the default: split f16 products, the cross terms of the 7- / 11-tap convs on 8-bit MFMAs),
+    /// 1 = f16x3 (three f16 MFMAs per product), 0 = f32 MFMA, 4 / 5 = one f16 / bf16 MFMA per product (opt-in reduced precision).
     pub fn set_conv_mode(&self, mode: i32) -> Result<(), Box<dyn Error>> {
         self.check(unsafe { kx_set_conv_mode(self.h, mode) })
     }
