@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
     // issued, so a fragment is requested two whole steps before its use and nothing ever moves between registers.  The
     // (chunk, tap) walk is flattened and unrolled by three for that.
 #ifdef KX_DA_STAMPS  // diagnostic build only (tools/stamp_timeline.py): per-workgroup phase stamps; nothing reads them back
-    unsigned long long st0 = 0, st1 = 0, st2 = 0, cyc0 = 0, acc_bar = 0;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, cyc0 = 0, acc_bar = 0, acc_wait = 0;
     if (a.stamps) {
         st0 = __builtin_amdgcn_s_memrealtime();
         cyc0 = __builtin_readcyclecounter();
@@ -695,6 +695,16 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
         // Per accumulator: cross terms of a group, then the pair's a_hi b_hi; groups and taps ascending.
         static_assert(W64, "S16: the 64-column window of the unrolled forms");
         constexpr int NB = 2 * NT, HS = (KT - 1) / 2, TB = KT * NB, NA = HS * NB, SB0 = (HS + 1) * NB;
+#ifdef KX_DA_STAMPS  // diagnostic build: 10 ns ticks a wave spends in the loop's barriers (o[7]) and in its ring waits (o[6])
+        unsigned long long tb0 = 0;
+#define F8_BAR_T0 if (a.stamps) tb0 = __builtin_amdgcn_s_memrealtime();
+#define F8_BAR_T1 if (a.stamps) acc_bar += __builtin_amdgcn_s_memrealtime() - tb0;
+#define F8_WAIT_T1 if (a.stamps) acc_wait += __builtin_amdgcn_s_memrealtime() - tb0;
+#else
+#define F8_BAR_T0
+#define F8_BAR_T1
+#define F8_WAIT_T1
+#endif
 #ifndef KX_F8_RH
 #define KX_F8_RH ((KT - 1) % 3 != 0 ? 3 : 4)
 #endif
@@ -788,13 +798,21 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
                 constexpr int c = FS::cross_of(p), xsl = c >= 0 ? c % RC : 0;
                 if constexpr (nb == 0) {
                     if constexpr (p == HS) {
+                        F8_BAR_T0
                         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier 1
+                        F8_BAR_T1
                         load_raw(ch0 + 2 < n_chunks ? ch0 + 2 : n_chunks - 1);
                         load_blk_h(p, 0, fh[e]);
                     }
-                    if constexpr (p == HS + 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier 2
+                    if constexpr (p == HS + 1) {
+                        F8_BAR_T0
+                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier 2
+                        F8_BAR_T1
+                    }
                     constexpr int ag_h = FS::age(0, p), ag_x = c >= 0 ? FS::age(1, c) : 63;
+                    F8_BAR_T0
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ag_h < ag_x ? ag_h : ag_x) : "memory");
+                    F8_WAIT_T1
                     __builtin_amdgcn_sched_barrier(0);
                     asm volatile("" : "+v"(hs[sl][0]), "+v"(hs[sl][1]));
                     if constexpr (c >= 0) asm volatile("" : "+v"(xs[xsl][0]), "+v"(xs[xsl][1]), "+v"(xs[xsl][2]), "+v"(xs[xsl][3]));
@@ -879,7 +897,9 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
                     }
                 }
             });
+            F8_BAR_T0
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier 3
+            F8_BAR_T1
             load_raw(ch0 + 3 < n_chunks ? ch0 + 3 : n_chunks - 1);
             load_blk_h(0, 0, fh[0]);
             load_blk_x(0, 0, fx[0]);
@@ -1459,7 +1479,7 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
         o[3] = __builtin_amdgcn_s_memrealtime();
         o[4] = __builtin_amdgcn_s_getreg(63492);  // HW_REG_HW_ID
         o[5] = __builtin_readcyclecounter() - cyc0;
-        o[6] = __builtin_amdgcn_s_getreg(63508);  // HW_REG_XCC_ID
+        o[6] = F8 ? acc_wait : __builtin_amdgcn_s_getreg(63508);  // HW_REG_XCC_ID; F8 forms: 10 ns ticks in the ring waits of the main loop (wave 0)
         o[7] = acc_bar;  // 10 ns ticks spent in the chunk barriers of the main loop (wave 0)
     }
 #endif

@@ -60,3 +60,9 @@ if len(sys.argv) > 3 and sys.argv[3] == "drain":  # KX_DBG=128: o[6] = stamp tak
     y = pre - st[2]
     print(f"epilogue issue part p50 {np.median(y):.1f} us (p10 {np.percentile(y,10):.1f}, p90 {np.percentile(y,90):.1f}); "
           f"drain of the stores after the last one was issued p50 {np.median(x):.1f} us (p10 {np.percentile(x,10):.1f}, p90 {np.percentile(x,90):.1f})")
+if len(sys.argv) > 3 and sys.argv[3] == "f8":  # F8 forms: o[7] = 10 ns ticks of wave 0 in the loop's barriers, o[6] = in its ring waits
+    bar = d[:, 7].astype(np.float64) / 100.0
+    wt = d[:, 6].astype(np.float64) / 100.0
+    loop = st[2] - st[1]
+    print(f"wave 0, main loop: in barriers p50 {np.median(bar):.1f} us ({100 * np.median(bar / loop):.1f} % of the loop), in ring waits p50 {np.median(wt):.1f} us "
+          f"({100 * np.median(wt / loop):.1f} %)")
