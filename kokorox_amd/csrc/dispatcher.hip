@@ -4,6 +4,10 @@
 //
 // The reference serves every request through one `Mutex<Session>` (kokorox/src/onn/ort_koko.rs:78; callers
 // kokorox-openai/src/lib.rs:370-439, kokorox-websocket/src/lib.rs:657-668): N clients = N sequential runs.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
 #include "dispatcher_core.h"
 #include "kx_handle.h"
 
@@ -99,7 +103,33 @@ struct ModelBackend {
             parts[(size_t)b] = static_cast<char*>(o.buf) + off;
             off += o.bytes[(size_t)b];
         }
-        kx::host_out_share(o.buf, parts.data(), B);
+        // A client that keeps (caches, leaks) one result keeps its whole batch's buffer page-locked.  Beyond KX_PINNED_LIVE_CAP_MB
+        // (default 4096) of such buffers still held, a batch's results are copied out into plain allocations instead -- the ~5 ms of
+        // host time per batch the sharing saves are the price of clients that do not give results back -- and the buffer returns
+        // to the pool at once.
+        static const long cap_mb = getenv("KX_PINNED_LIVE_CAP_MB") ? atol(getenv("KX_PINNED_LIVE_CAP_MB")) : 4096;
+        if (kx::host_out_live_bytes() + (size_t)off > (size_t)(cap_mb > 0 ? cap_mb : 0) * (size_t(1) << 20)) {
+            std::vector<void*> copies;
+            copies.reserve((size_t)B);
+            bool ok = true;
+            for (int b = 0; b < B && ok; ++b) {
+                void* q = malloc((size_t)(o.bytes[(size_t)b] > 0 ? o.bytes[(size_t)b] : 1));
+                ok = q != nullptr;
+                if (ok) {
+                    memcpy(q, parts[(size_t)b], (size_t)o.bytes[(size_t)b]);
+                    copies.push_back(q);
+                }
+            }
+            if (ok) {
+                parts = copies;
+                kx::host_out_free(o.buf);
+            } else {  // (out of pageable memory: share after all)
+                for (void* q : copies) free(q);
+                kx::host_out_share(o.buf, parts.data(), B);
+            }
+        } else {
+            kx::host_out_share(o.buf, parts.data(), B);
+        }
         for (int b = 0; b < B; ++b) {
             Request* r = batch[(size_t)b];
             r->out = parts[(size_t)b];

@@ -266,6 +266,9 @@ void host_out_free(void* p);
 // n pointers into one host_out_alloc'd buffer handed to n owners: each is released with host_out_free, the buffer goes back
 // to the pool with the last one (parts[0] may be the buffer's own address)
 void host_out_share(void* base, void* const* parts, int n);
+// page-locked bytes of shared batch buffers that owners still hold a part of (what the dispatcher caps: a client that keeps one
+// result keeps its whole batch's buffer pinned)
+size_t host_out_live_bytes();
 void launch_fill_style_rows(float* dst, long bs, int ld, int row0, const float* styles, int style_off,
                             const int* lens, int B, int Tmax, hipStream_t s);
 void launch_copy_rows(const float* src, long sbs, int sld, float* dst, long dbs, int dld, int rows, LenMap len,

@@ -1905,6 +1905,7 @@ struct HostPool {
     std::map<void*, void*> alias;            // pointer handed to an owner -> the shared buffer it lies in (host_out_share)
     std::map<void*, int> refs;               // shared buffer -> owners still holding a part
     size_t idle_bytes = 0;
+    size_t live_shared = 0;                  // capacity of the shared buffers in `refs`
     static constexpr size_t kMaxIdle = size_t(1) << 30;
     ~HostPool() {
         for (auto& kv : free_list) (void)hipHostFree(kv.second);
@@ -1950,6 +1951,14 @@ void host_out_share(void* base, void* const* parts, int n) {
     int distinct = 0;
     for (int i = 0; i < n; ++i) distinct += P.alias.emplace(parts[i], base).second ? 1 : 0;
     P.refs[base] = distinct;
+    auto it = P.cap.find(base);
+    if (it != P.cap.end()) P.live_shared += it->second;
+}
+
+size_t host_out_live_bytes() {
+    HostPool& P = host_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    return P.live_shared;
 }
 
 void host_out_free(void* p) {
@@ -1966,6 +1975,8 @@ void host_out_free(void* p) {
             if (rf != P.refs.end() && --rf->second > 0) return;
             if (rf != P.refs.end()) P.refs.erase(rf);
             p = base;
+            auto cb = P.cap.find(base);
+            if (cb != P.cap.end()) P.live_shared -= cb->second < P.live_shared ? cb->second : P.live_shared;
         }
         auto it = P.cap.find(p);
         if (it != P.cap.end()) {

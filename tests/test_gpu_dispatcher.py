@@ -162,3 +162,41 @@ def test_32_clients_mixed_voices_and_formats_over_two_models(blob_path, hip_mode
     assert np.abs(out[c0] - audio.numpy()).max() < 1e-4
     for m in ms:
         m.close()
+
+
+def test_results_are_copied_out_once_too_many_shared_buffers_are_held(blob_path):
+    """Dispatcher results point into their batch's page-locked buffer; a client that keeps results keeps those buffers pinned.
+    Beyond KX_PINNED_LIVE_CAP_MB of them the dispatcher copies a batch's results out instead.  With the cap at 0 every
+    batch takes that path: same bytes as the same requests run alone, and the pool holds nothing afterwards (own process: the cap is
+    read once)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import threading, numpy as np
+from kokorox_amd import hip_koko as hk
+from kokorox_amd import weights as W
+from oracle import kokoro_ref as R
+m = hk.HipKoko.new(%r)
+voices = W.synthetic_voices(4)
+reqs = [(R.synthetic_inputs(1, 8 + 3 * i, seed=300 + i)[0], voices[i %% 4, 8 + 3 * i, 0], 1.0, 50 + i) for i in range(8)]
+d = hk.Dispatcher([m], max_batch=8, max_wait_us=200000)
+out = [None] * len(reqs)
+def client(i):
+    out[i] = d.submit(*reqs[i])
+th = [threading.Thread(target=client, args=(i,)) for i in range(len(reqs))]
+[t.start() for t in th]
+[t.join(timeout=300) for t in th]
+st = d.stats()
+d.close()
+assert st["batches"] < len(reqs), st
+m.set_utterance_base(0)
+for i, (ids, style, speed, seed) in enumerate(reqs):
+    np.testing.assert_array_equal(out[i], m.infer([list(ids)], [list(style)], speed, seed=seed))
+m.close()
+print("copied out ok")
+""" % blob_path
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, KX_PINNED_LIVE_CAP_MB="0"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "copied out ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
