@@ -655,7 +655,7 @@ def main():
             # (the family mixes launches at one MFMA per product -- the decoder / generator direct-A convs -- with launches
             # at three: `achieved` is algorithmic FLOPs over time, the issue factor is stated, no pipe utilisation is derived)
             ach3 = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
-            progress(f"reduced-precision steps ({label}): {w3:.3f} s")
+            progress(f"{'other-mode' if mode == 1 else 'reduced-precision'} steps ({label}): {w3:.3f} s")
             return {"value": audio_s_per_step * a.steps / w3, "unit": "x realtime", "ms_per_step": w3 / a.steps * 1e3,
                     "roofline": {"bound": "mfma", "achieved": ach3, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                                  "frac": ach3 / PEAK_F16_MFMA_TFLOPS, "mfma_issue_factor": "1 on the direct-A convs, 3 elsewhere",
