@@ -19,8 +19,13 @@
 // left is ONE barrier per 16-channel chunk (the input images alternate between two LDS buffers).
 // B fragments: a three-entry ring over the column tiles; a tile's three MFMAs run back to back on its accumulator and the
 // fragments of the tile two further on are read under them.
-// Four forms of the main loop:
-//   * S16 (snake convs with 11 taps, default; KX_DA_S16=0 switches it off): v_mfma_f32_16x16x32_f16 with K = 16 channels x two
+// Five forms of the main loop:
+//   * F8 (round 5, the default mode f16f8: every 7- and 11-tap snake conv whose layer carries an 8-bit cross image): the S16 frame
+//     below with a_hi b_hi on v_mfma_f32_16x16x32_f16 and the two cross terms of 16 channels x 4 taps on ONE
+//     v_mfma_scale_f32_16x16x128_f8f6f4 -- two MFMA-equivalents per product instead of three, ~2^-17 per product instead of 2^-22
+//     (see "S16 form, f16f8"); rings and input prefetch are buffer loads, the snake takes sin^2 from v_cos_f32;
+//   * S16 (f16x3 mode: snake convs with 11 taps and the un-dilated 7-tap ones; KX_DA_S16=0 switches it off): v_mfma_f32_16x16x32_f16
+//     with K = 16 channels x two
 //     taps, on a 128 x 192 tile (128 x 128 on small grids) with 64-column statistics slots; the one form whose results are not
 //     bit-identical to the others (one instruction sums 32 products) -- its two tile widths are identical to each other;
 //   * W2 (the 256-column tile's compile-time tap counts, default): the four waves as 2 x 2, each 64 rows x 128 columns, so that a
