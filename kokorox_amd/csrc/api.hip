@@ -34,7 +34,7 @@ static void check_device(int device_id) {
 
 extern "C" {
 
-const char* kx_version(void) { return "kokorox-hip 0.3 (gfx950; conv modes: f16x3 split MFMA [default], f32 MFMA, f16 / bf16 reduced precision [opt-in])"; }
+const char* kx_version(void) { return "kokorox-hip 0.4 (gfx950; conv modes: f16f8 split MFMA with 8-bit cross terms [default], f16x3 split MFMA, f32 MFMA, f16 / bf16 reduced precision [opt-in])"; }
 
 int kx_init(int device_id, char* err, size_t err_len) {
     return guarded_free(err, err_len, [&] { check_device(device_id); });
