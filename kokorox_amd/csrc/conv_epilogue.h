@@ -269,7 +269,8 @@ __device__ __forceinline__ void conv_store_rmw(const ConvArgs& a, f32x16 (&acc)[
 // SC: scatter(n) writes the wave's 32 x 32 tile n of the group into scr, element (row, column) at scr[row * P + column]
 // (P: pitch in floats, a multiple of 4) -- the only part that knows the MFMA's C/D layout.
 // GT: 32-column tiles of the group (4 = 128 columns; 2 = the 64-column groups of the S16 form)
-template <int LOADS, int P, class SC, int GT = 4>
+// AUXV: cache policy of the residual / running-sum loads and of the stores (2 = non-temporal: ConvArgs::epi_stream)
+template <int LOADS, int P, class SC, int GT = 4, int AUXV = 0>
 __device__ __forceinline__ void conv_store_wide4_t(const ConvArgs& a, SC&& scatter, float acc_scale, int b, int row0, int col0,
                                                    int lane, int stat_slot, float* scr) {
     using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -282,7 +283,7 @@ __device__ __forceinline__ void conv_store_wide4_t(const ConvArgs& a, SC&& scatt
     auto yterm = [&](int n, int i) { return 4u * ((unsigned)(row0 + 8 * i) * (unsigned)a.y_ld + (unsigned)(col0 + 32 * n)); };
     auto rterm = [&](int n, int i) { return 4u * ((unsigned)(row0 + 8 * i) * (unsigned)a.r_ld + (unsigned)(col0 + 32 * n)); };
     auto ld4 = [&](buf_rsrc rs, unsigned lane_off, unsigned uni) {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, uni, KX_EPI_LD_AUX));
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, uni, AUXV ? AUXV : KX_EPI_LD_AUX));
     };
     float bias4[4];
 #pragma unroll
@@ -325,7 +326,7 @@ __device__ __forceinline__ void conv_store_wide4_t(const ConvArgs& a, SC&& scatt
                     rq[i] = __builtin_fmaf(x, x, rq[i]);
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ybuf, ylane,
-                                                       yterm(n, i), KX_EPI_ST_AUX);
+                                                       yterm(n, i), AUXV ? AUXV : KX_EPI_ST_AUX);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -532,6 +533,24 @@ __device__ __forceinline__ void conv_store_group16(const ConvArgs& a, f32x4v (&a
     };
     if (KX_EPI_WIDE && a.store == ST_NORMAL && full && a.merge_T == 0 && !(a.dbg & 16384)) {
         const bool res = a.resid != nullptr, accum = a.accum != 0;
+        // epi_stream (launch-uniform): the output tensor is far larger than L2 and MALL -- the next layer reads it back from HBM
+        // whatever happens -- so its stores and the residual loads are non-temporal (measured at batch 64: -0.4 ms per step on the
+        // F8 forms; on every direct-A kernel alike: +5 ms, the 256-row layers' row tiles share lines; at batch 1, where the tensors
+        // do fit, +0.1 ms: profiles/r05_f16f8_form.txt)
+        if (a.epi_stream) {
+            if (res && accum) {
+                conv_store_wide4_t<2, 36, decltype(scatter)&, GT, 2>(a, scatter, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
+                return;
+            }
+            if (res && !accum) {
+                conv_store_wide4_t<1, 36, decltype(scatter)&, GT, 2>(a, scatter, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
+                return;
+            }
+            if (!res && !accum) {
+                conv_store_wide4_t<0, 36, decltype(scatter)&, GT, 2>(a, scatter, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
+                return;
+            }
+        }
         if (res && accum) {
             conv_store_wide4_t<2, 36, decltype(scatter)&, GT>(a, scatter, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
             return;
