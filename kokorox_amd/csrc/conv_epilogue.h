@@ -348,17 +348,15 @@ __device__ __forceinline__ void conv_store_wide4_t(const ConvArgs& a, SC&& scatt
     }
 }
 
-template <int LOADS>
+template <int LOADS, int AUXV = 0>
 __device__ __forceinline__ void conv_store_wide4(const ConvArgs& a, f32x16 (&acc)[1][4], float acc_scale, int b, int row0,
                                                  int col0, int lane, int stat_slot, float* scr) {
     const int r = lane & 31, h = lane >> 5;
-    conv_store_wide4_t<LOADS, 32>(
-        a,
-        [&](int n) __attribute__((always_inline)) {
+    auto sc = [&](int n) __attribute__((always_inline)) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) scr[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[0][n][e];
-        },
-        acc_scale, b, row0, col0, lane, stat_slot, scr);
+        for (int e = 0; e < 16; ++e) scr[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[0][n][e];
+    };
+    conv_store_wide4_t<LOADS, 32, decltype(sc)&, 4, AUXV>(a, sc, acc_scale, b, row0, col0, lane, stat_slot, scr);
 }
 
 // Dispatcher of the direct-A kernels for one 32-row x 128-column group: the wide form where it applies (plain channel-major
@@ -496,6 +494,20 @@ __device__ __forceinline__ void conv_store_group(const ConvArgs& a, f32x16 (&acc
     if (KX_EPI_WIDE && a.store == ST_NORMAL && full && a.merge_T == 0 && !(a.dbg & 16384)) {
         const int lane = r + 32 * h;
         const bool res = a.resid != nullptr, accum = a.accum != 0;
+        if (a.epi_stream) {  // (see conv_store_group16)
+            if (res && accum) {
+                conv_store_wide4<2, 2>(a, acc, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
+                return;
+            }
+            if (res && !accum) {
+                conv_store_wide4<1, 2>(a, acc, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
+                return;
+            }
+            if (!res && !accum) {
+                conv_store_wide4<0, 2>(a, acc, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
+                return;
+            }
+        }
         if (res && accum) {
             conv_store_wide4<2>(a, acc, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
             return;
@@ -535,8 +547,8 @@ __device__ __forceinline__ void conv_store_group16(const ConvArgs& a, f32x4v (&a
         const bool res = a.resid != nullptr, accum = a.accum != 0;
         // epi_stream (launch-uniform): the output tensor is far larger than L2 and MALL -- the next layer reads it back from HBM
         // whatever happens -- so its stores and the residual loads are non-temporal (measured at batch 64: -0.4 ms per step on the
-        // F8 forms; on every direct-A kernel alike: +5 ms, the 256-row layers' row tiles share lines; at batch 1, where the tensors
-        // do fit, +0.1 ms: profiles/r05_f16f8_form.txt)
+        // F8 forms, -0.3 more on the 3-tap forms; WITHOUT the size rule, on every direct-A launch alike: +5 ms -- the token-axis and
+        // decoder tensors do fit the caches --; at batch 1 +0.1 ms: profiles/r05_f16f8_form.txt)
         if (a.epi_stream) {
             if (res && accum) {
                 conv_store_wide4_t<2, 36, decltype(scatter)&, GT, 2>(a, scatter, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);

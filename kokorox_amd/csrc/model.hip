@@ -639,10 +639,11 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     // f16f8 mode (opt-in): the layers that carry an 8-bit cross image run two MFMA-equivalents per product instead of three
     a.w8x = conv_mode == CONV_F16F8 ? w.w8x : nullptr;
     a.hwcos = conv_mode == CONV_F16F8 && o.act == ACT_SNAKE && w.K == 3 && w.BM == 128;
-    // outputs of the f16f8 kernels that no cache can hold until the next layer reads them (> 512 MB: L2 is 32 MB, MALL 256 MB) are
-    // streamed (non-temporal epilogue accesses); smaller ones (small batches) stay cacheable
+    // outputs that no cache can hold until the next layer reads them (> 512 MB: L2 is 32 MB, MALL 256 MB) are streamed by the direct-A
+    // kernels' interior stores (non-temporal stores and residual loads); smaller ones (small batches, the token axis, the decoder)
+    // stay cacheable
     static const long stream_mb = getenv("KX_EPI_STREAM_MB") ? atol(getenv("KX_EPI_STREAM_MB")) : 512;
-    a.epi_stream = a.w8x != nullptr && stream_mb >= 0 && (double)B_ * w.rows * out.ld * 4.0 > (double)stream_mb * 1048576.0;
+    a.epi_stream = f16 && stream_mb >= 0 && (double)B_ * w.rows * out.ld * 4.0 > (double)stream_mb * 1048576.0;
     a.n_chunks16 = w.n_chunks16;
     static const int xcd_swz = getenv("KX_XCD_SWIZZLE") ? atoi(getenv("KX_XCD_SWIZZLE")) : 1;
     a.xcd_swizzle = xcd_swz;
