@@ -361,7 +361,7 @@ __device__ __forceinline__ void conv_store_wide4(const ConvArgs& a, f32x16 (&acc
 
 // Dispatcher of the direct-A kernels for one 32-row x 128-column group: the wide form where it applies (plain channel-major
 // store, the whole group inside the tensor), else the general forms below.
-template <int EB>
+template <int EB, bool STREAM = false>
 __device__ __forceinline__ void conv_store_group(const ConvArgs& a, f32x16 (&acc)[1][4], float acc_scale, int b, int row0,
                                                  int col0, int r, int h, int ncols, int Lout, int stat_slot, float2* stat_scr,
                                                  float* wide_scr);
@@ -486,7 +486,9 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs& a, f32x16 (&acc)
 #ifndef KX_EPI_WIDE
 #define KX_EPI_WIDE 1
 #endif
-template <int EB>
+// STREAM: the kernel has the non-temporal variant of the wide store (the tile forms of chip-filling grids only: a launch on the
+// small-grid forms never has an output large enough to be streamed, and their 168-register budget has no room for a second copy)
+template <int EB, bool STREAM>
 __device__ __forceinline__ void conv_store_group(const ConvArgs& a, f32x16 (&acc)[1][4], float acc_scale, int b, int row0,
                                                  int col0, int r, int h, int ncols, int Lout, int stat_slot, float2* stat_scr,
                                                  float* wide_scr) {
@@ -494,18 +496,20 @@ __device__ __forceinline__ void conv_store_group(const ConvArgs& a, f32x16 (&acc
     if (KX_EPI_WIDE && a.store == ST_NORMAL && full && a.merge_T == 0 && !(a.dbg & 16384)) {
         const int lane = r + 32 * h;
         const bool res = a.resid != nullptr, accum = a.accum != 0;
-        if (a.epi_stream) {  // (see conv_store_group16)
-            if (res && accum) {
-                conv_store_wide4<2, 2>(a, acc, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
-                return;
-            }
-            if (res && !accum) {
-                conv_store_wide4<1, 2>(a, acc, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
-                return;
-            }
-            if (!res && !accum) {
-                conv_store_wide4<0, 2>(a, acc, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
-                return;
+        if constexpr (STREAM) {
+            if (a.epi_stream) {  // (see conv_store_group16)
+                if (res && accum) {
+                    conv_store_wide4<2, 2>(a, acc, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
+                    return;
+                }
+                if (res && !accum) {
+                    conv_store_wide4<1, 2>(a, acc, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
+                    return;
+                }
+                if (!res && !accum) {
+                    conv_store_wide4<0, 2>(a, acc, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
+                    return;
+                }
             }
         }
         if (res && accum) {
@@ -529,7 +533,7 @@ __device__ __forceinline__ void conv_store_group(const ConvArgs& a, f32x16 (&acc
 // same LDS transpose (pitch 36: the four row groups of one write land on different banks) and is otherwise the code above; the
 // general forms get the group re-laid into the 32 x 32 C/D layout through the same scratch first.
 using f32x4v = __attribute__((ext_vector_type(4))) float;
-template <int EB, int NBT, int GT>
+template <int EB, int NBT, int GT, bool STREAM = false>
 __device__ __forceinline__ void conv_store_group16(const ConvArgs& a, f32x4v (&acc)[2][NBT], const int blk0, float acc_scale, int b,
                                                    int row0, int col0, int lane, int ncols, int Lout, int stat_slot,
                                                    float2* stat_scr, float* wide_scr) {
@@ -549,18 +553,20 @@ __device__ __forceinline__ void conv_store_group16(const ConvArgs& a, f32x4v (&a
         // whatever happens -- so its stores and the residual loads are non-temporal (measured at batch 64: -0.4 ms per step on the
         // F8 forms, -0.3 more on the 3-tap forms; WITHOUT the size rule, on every direct-A launch alike: +5 ms -- the token-axis and
         // decoder tensors do fit the caches --; at batch 1 +0.1 ms: profiles/r05_f16f8_form.txt)
-        if (a.epi_stream) {
-            if (res && accum) {
-                conv_store_wide4_t<2, 36, decltype(scatter)&, GT, 2>(a, scatter, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
-                return;
-            }
-            if (res && !accum) {
-                conv_store_wide4_t<1, 36, decltype(scatter)&, GT, 2>(a, scatter, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
-                return;
-            }
-            if (!res && !accum) {
-                conv_store_wide4_t<0, 36, decltype(scatter)&, GT, 2>(a, scatter, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
-                return;
+        if constexpr (STREAM) {
+            if (a.epi_stream) {
+                if (res && accum) {
+                    conv_store_wide4_t<2, 36, decltype(scatter)&, GT, 2>(a, scatter, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
+                    return;
+                }
+                if (res && !accum) {
+                    conv_store_wide4_t<1, 36, decltype(scatter)&, GT, 2>(a, scatter, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
+                    return;
+                }
+                if (!res && !accum) {
+                    conv_store_wide4_t<0, 36, decltype(scatter)&, GT, 2>(a, scatter, acc_scale, b, row0, col0, lane, stat_slot, wide_scr);
+                    return;
+                }
             }
         }
         if (res && accum) {

@@ -1459,13 +1459,13 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
         // 64-column groups = the statistics slots of this form (both of its tile widths: batch invariance)
         static_for<0, NT / 2>([&](auto gc) __attribute__((always_inline)) {
             constexpr int g2 = decltype(gc)::value;
-            conv_store_group16<EPI_ROWS, NB16, 2>(a, acc16, 4 * g2, a.w_unscale, b, ct * BM + wave * 32, t0 + 64 * g2, lane, ncols, Lout,
+            conv_store_group16<EPI_ROWS, NB16, 2, NT == 6>(a, acc16, 4 * g2, a.w_unscale, b, ct * BM + wave * 32, t0 + 64 * g2, lane, ncols, Lout,
                                                   tile_x * (NT / 2) + g2, stat_scr, wide_scr);
         });
     } else if constexpr (W2) {
-        conv_store_group<EPI_ROWS>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][0]), a.w_unscale, b, ct * BM + wr2 * 64, t0 + 128 * wc2, r,
+        conv_store_group<EPI_ROWS, true>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][0]), a.w_unscale, b, ct * BM + wr2 * 64, t0 + 128 * wc2, r,
                                    h, ncols, Lout, tile_x * 2 + wc2, stat_scr, wide_scr);
-        conv_store_group<EPI_ROWS>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][4]), a.w_unscale, b, ct * BM + wr2 * 64 + 32, t0 + 128 * wc2,
+        conv_store_group<EPI_ROWS, true>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][4]), a.w_unscale, b, ct * BM + wr2 * 64 + 32, t0 + 128 * wc2,
                                    r, h, ncols, Lout, tile_x * 2 + wc2, stat_scr, wide_scr);
     } else if constexpr (NT == 8) {
         conv_store_group<EPI_ROWS>(a, *reinterpret_cast<f32x16(*)[1][4]>(&acc[0][0]), a.w_unscale, b, ct * BM + wave * 32, t0, r, h,

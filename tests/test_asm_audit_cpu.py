@@ -106,6 +106,14 @@ def _audit_no_touch_before_wait(lines):
     return bad
 
 
+def _audit_spills(name, lines):
+    """No spill between the first and the last MFMA (a spill reload is a vector-memory operation the hand-counted waits do not know of);
+    the epilogue may park ONE 16-byte value (round 5: the 2 x 2 forms carry the streaming and the cacheable wide store, twice each)."""
+    mfi = [i for i, ln in enumerate(lines) if "v_mfma" in ln]
+    assert not any("scratch_" in ln for ln in lines[mfi[0]:mfi[-1] + 1]), f"{name} spills inside the main loop"
+    assert sum(1 for ln in lines if "scratch_" in ln) <= 2, f"{name}: more than one spilled value"
+
+
 def _prefetch_batches(lines):
     """Sizes of the runs of scalar-dword vector loads that follow an s_barrier of the MAIN LOOP (the input prefetch of a
     chunk boundary).  A run ends at the next MFMA or the next barrier, whichever comes first in the text: the compiler may
@@ -141,7 +149,7 @@ def test_direct_a_conv_assembly(tmp_path, src):
     # (round 5: + the hardware-cosine forms of the 3-tap snake convs, two tile widths in the main unit, one in the 2 x 2 unit)
     assert len(ks) == {"conv_f16x3_da_w2.hip": 5, "conv_f16x3_da_s16.hip": 4, "conv_f16x3_da_p1.hip": 28}.get(src, 16), sorted(ks)
     for name, lines in ks.items():
-        assert not any("scratch_" in ln for ln in lines), f"{name} spills"
+        _audit_spills(name, lines)
         bad = _audit_no_touch_before_wait(lines)
         assert not bad, f"{name}: ring registers touched before their wait: {bad[:3]}"
         m = re.search(r"da_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb[01]E", name)
@@ -296,7 +304,7 @@ def test_pre_split_kernels_assembly(tmp_path):
     ks = _kernels(_asm("conv_f16x3_da_pre.hip", tmp_path))
     assert len(ks) == 4, sorted(ks)
     for name, lines in ks.items():
-        assert not any("scratch_" in ln for ln in lines), f"{name} spills"
+        _audit_spills(name, lines)
         bad = _audit_no_touch_before_wait(lines)
         assert not bad, f"{name}: ring registers touched before their wait: {bad[:3]}"
         body = [ln.strip() for ln in lines]
