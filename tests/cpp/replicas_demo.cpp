@@ -45,7 +45,10 @@ int main(int argc, char** argv) {
     std::vector<int> devices(n_models);
     for (int i = 0; i < n_models; ++i) devices[i] = i % visible;
     try {
+        // (progress on stderr: should this demo ever stall, the test's time-out report says where)
+        fprintf(stderr, "stage: creating %d replicas\n", n_models);
         std::vector<kokorox::HipKoko> models = kokorox::HipKoko::replicas(argv[1], devices);
+        fprintf(stderr, "stage: replicas ready\n");
         std::vector<kx_model*> hs;
         for (auto& m : models) hs.push_back(m.handle());
         char err[256] = {0};
@@ -72,15 +75,20 @@ int main(int argc, char** argv) {
                 }
             });
         for (auto& t : th) t.join();
+        fprintf(stderr, "stage: requests answered\n");
         int64_t nr = 0, nb = 0, mb = 0;
         kx_dispatcher_stats(d, &nr, &nb, &mb);
         kx_dispatcher_destroy(d);
+        fprintf(stderr, "stage: dispatcher destroyed\n");
         printf("models=%d requests=%lld\n", n_models, (long long)nr);
         for (int i = 0; i < n_req; ++i)
             printf("req%d rc=%d samples=%lld fnv1a=%016llx\n", i, rcs[i], (long long)lens[i], (unsigned long long)sums[i]);
+        fflush(stdout);
+        fprintf(stderr, "stage: destroying the models\n");
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;
     }
+    fprintf(stderr, "stage: done\n");
     return 0;
 }

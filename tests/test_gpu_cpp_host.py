@@ -45,7 +45,13 @@ def test_cpp_replicas_and_dispatcher_over_two_models(hip_model, blob_path, golde
     g = golden["hello_world"]
     style = str(tmp_path / "style.f32")
     g["style"].astype("<f4").tofile(style)
-    r = subprocess.run([exe, blob_path, style, "2"], capture_output=True, text=True, timeout=300)
+    try:
+        r = subprocess.run([exe, blob_path, style, "2"], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, KX_TRACE_DTOR="1"))
+    except subprocess.TimeoutExpired as e:  # (say where it stalled: the demo and the model destructor report their stages on stderr)
+        err = e.stderr.decode() if isinstance(e.stderr, bytes) else (e.stderr or "")
+        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        raise AssertionError("replicas demo stalled; stderr so far:\n" + err[-3000:] + "\nstdout so far:\n" + out[-1500:])
     assert r.returncode == 0, r.stderr
     assert "models=2 requests=8" in r.stdout
     row = [0, 50, 83, 54, 156, 57, 135, 3, 16, 65, 156, 87, 158, 54, 46, 5, 0]
