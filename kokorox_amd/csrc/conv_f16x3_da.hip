@@ -140,14 +140,11 @@ struct F8Sched {
     }
 };
 
-template <int ACT, int KT, int NTT, bool P1, bool W2 = false, bool S16 = false, bool PRE = false, bool BF = false, bool F8 = false, bool HC = false>
+template <int ACT, int KT, int NTT, bool P1, bool W2 = false, bool S16 = false, bool PRE = false, bool BF = false, bool F8 = false>
 __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_da_kernel(const ConvArgs a) {
     static_assert(!BF || P1, "BF: a form of the reduced-precision kernels only");
     static_assert(!F8 || (S16 && KT % 4 == 3), "F8: a form of the S16 loop; tap groups of four with one padding slot");
-    // HC: the snake's sin^2 from the hardware cosine, as the F8 forms take it (the 3-tap snake convs of the f16f8 mode: their
-    // products stay f16x3, their transform -- which bounds them -- loses a quarter of its vector instructions)
-    static_assert(!HC || (ACT == ACT_SNAKE && !F8 && !P1 && !PRE), "HC: a snake form of the f16x3 kernels");
-    constexpr bool HWC = (F8 || HC) && KX_F8_HWCOS;
+    constexpr bool HWC = F8 && KX_F8_HWCOS;
     static_assert(!PRE || (!P1 && !S16 && ACT == ACT_NONE), "PRE: the activation lives in the image; f16x3 forms on 32x32x16 only");
     static_assert(!W2 || (KT >= 3 && (KT & 1) && NTT == 8), "W2: odd compile-time tap counts on the 256-column tile");
     static_assert(!S16 || (KT >= 3 && (KT & 1) && !P1 && !W2), "S16: odd compile-time tap counts, three MFMAs per product, 4 x 1 waves");
@@ -785,7 +782,7 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
 #ifndef KX_F8_I0B
 #define KX_F8_I0B 8
 #endif
-        constexpr int I0A = (KT >= 9 ? KX_F8_I0A_LONG : KX_F8_I0A_MID) * NT / 8, I0B = KX_F8_I0B * NT / 8;
+        constexpr int I0A = (KT >= 9 ? KX_F8_I0A_LONG : (KT >= 5 ? KX_F8_I0A_MID : 4)) * NT / 8, I0B = (KT >= 5 ? KX_F8_I0B : 2) * NT / 8;
         static_assert(I0A < NA && I0B < NA, "f16f8: the transform needs blocks to ride on");
 #ifndef KX_F8_G
 #define KX_F8_G 2
@@ -1516,9 +1513,9 @@ constexpr bool DA_F8 = true;
 constexpr bool DA_F8 = false;
 #endif
 
-template <int ACT, int KT, int NTT, bool W2X = DA_W2, bool PREX = false, bool BFX = false, bool HCX = false>
+template <int ACT, int KT, int NTT, bool W2X = DA_W2, bool PREX = false, bool BFX = false>
 static void launch_da_inst(const ConvArgs& a, int B, int max_cols, hipStream_t s) {
-    auto kern = conv1d_f16x3_da_kernel<ACT, KT, NTT, DA_P1, W2X, DA_S16, PREX, BFX, DA_F8, HCX>;
+    auto kern = conv1d_f16x3_da_kernel<ACT, KT, NTT, DA_P1, W2X, DA_S16, PREX, BFX, DA_F8>;
     constexpr int BN = 32 * NTT;
     // two input buffers (48 / 32 KiB), and never less than the statistics scratch of the epilogue (4 waves x 8.25 KiB)
     constexpr size_t lds_x = 16 * (size_t)2 * 4 * (BN + 128), lds_scr = 4 * 32 * 33 * sizeof(float2);
@@ -1560,8 +1557,14 @@ void launch_conv1d_f16x3_da_pre(const ConvArgs& a, int B, int max_cols, hipStrea
 }
 #elif defined(KX_DA_F8)
 // The f16f8 forms of the S16 loop (conv_f16x3_da_f8.hip defines KX_DA_S16 and KX_DA_F8 and includes this file): the S16 shapes
-// whose tap count is 3 mod 4 (11 and 7: all of them), when the layer carries an 8-bit cross image (ConvArgs::w8x, CONV_F16F8).
-bool conv16_da_f8_shape(int K, int dil) { return (K == 11 || K == 7) && (K - 1) * dil <= 64; }
+// whose tap count is 3 mod 4 (11, 7 and 3: all of them), when the layer carries an 8-bit cross image (ConvArgs::w8x, CONV_F16F8).
+// (the 3-tap snake convs are bound by their transform, not by the matrix pipe; on this form they still gain 6 % -- 12.8 -> 12.0 ms
+// over the six shapes -- from the hardware cosine, the shorter MFMA stream and the 16 x 16 shapes' clock; KX_F8_K3=0: the 2 x 2 f16x3 form)
+static bool f8_k3() {
+    static const int on = getenv("KX_F8_K3") ? atoi(getenv("KX_F8_K3")) : 1;
+    return on != 0;
+}
+bool conv16_da_f8_shape(int K, int dil) { return (K == 11 || K == 7 || (K == 3 && f8_k3())) && (K - 1) * dil <= 64; }
 void launch_conv1d_f16x3_da_f8(const ConvArgs& a, int B, int max_cols, hipStream_t s, int bn) {
     KX_REQUIRE(a.w8x != nullptr && conv16_da_f8_shape(a.K, a.dil) && a.act == ACT_SNAKE && a.stride == 1 && a.merge_T == 0 && !a.prec1 &&
                    a.n_chunks16 >= 2 && (a.n_chunks16 & 1) == 0,
@@ -1571,9 +1574,12 @@ void launch_conv1d_f16x3_da_f8(const ConvArgs& a, int B, int max_cols, hipStream
     if (a.K == 11) {
         if (bn == 192) launch_da_inst<ACT_SNAKE, 11, 6>(a, B, max_cols, s);
         else launch_da_inst<ACT_SNAKE, 11, 4>(a, B, max_cols, s);
-    } else {
+    } else if (a.K == 7) {
         if (bn == 192) launch_da_inst<ACT_SNAKE, 7, 6>(a, B, max_cols, s);
         else launch_da_inst<ACT_SNAKE, 7, 4>(a, B, max_cols, s);
+    } else {
+        if (bn == 192) launch_da_inst<ACT_SNAKE, 3, 6>(a, B, max_cols, s);
+        else launch_da_inst<ACT_SNAKE, 3, 4>(a, B, max_cols, s);
     }
 }
 #elif defined(KX_DA_S16)
@@ -1589,7 +1595,7 @@ bool conv16_da_s16_shape(int BM, int K, int dil, int stride, int act, int n_chun
     // layer's shape alone, never on the batch, so an utterance's bits do not depend on what it is batched with.
     // pmode: 0 = f16x3, 1 = a reduced-precision launch (never this form), 2 = f16f8 (the layer carries an 8-bit cross image: every
     // 7-tap conv takes the form -- with two MFMA-equivalents per product the dilated ones gain 18 % on it instead of losing 3 %)
-    const bool taps = K == 11 || (K == 7 && dil == 1 && on == 1) || (K == 7 && pmode == 2);
+    const bool taps = K == 11 || (K == 7 && dil == 1 && on == 1) || (K == 7 && pmode == 2) || (K == 3 && pmode == 2 && conv16_da_f8_shape(3, dil));
     return on && da && st && BM == 128 && stride == 1 && !merged && pmode != 1 && act == ACT_SNAKE && taps && (K - 1) * dil <= 64 &&
            n_chunks16 >= 2 && (n_chunks16 & 1) == 0;
 }
@@ -1619,7 +1625,6 @@ void launch_conv1d_f16x3_da_w2(const ConvArgs& a, int B, int max_cols, hipStream
     if (a.act == ACT_LEAKY) launch_da_inst<ACT_LEAKY, 3, 8>(a, B, max_cols, s);
     else if (a.K == 11) launch_da_inst<ACT_SNAKE, 11, 8>(a, B, max_cols, s);
     else if (a.K == 7) launch_da_inst<ACT_SNAKE, 7, 8>(a, B, max_cols, s);
-    else if (a.hwcos) launch_da_inst<ACT_SNAKE, 3, 8, true, false, false, true>(a, B, max_cols, s);  // (f16f8 mode: hardware cosine)
     else launch_da_inst<ACT_SNAKE, 3, 8>(a, B, max_cols, s);
 }
 #else
@@ -1649,9 +1654,6 @@ static void launch_da_ntt(const ConvArgs& a, int B, int max_cols, hipStream_t s)
     if (a.act == ACT_SNAKE) {
         if (st && w64 && a.K == 11) launch_da_inst<ACT_SNAKE, 11, NTT, DA_W2, false, BFX>(a, B, max_cols, s);
         else if (st && w64 && a.K == 7) launch_da_inst<ACT_SNAKE, 7, NTT, DA_W2, false, BFX>(a, B, max_cols, s);
-#ifndef KX_DA_P1
-        else if (st && w64 && a.K == 3 && a.hwcos) launch_da_inst<ACT_SNAKE, 3, NTT, DA_W2, false, false, true>(a, B, max_cols, s);
-#endif
         else if (st && w64 && a.K == 3) launch_da_inst<ACT_SNAKE, 3, NTT, DA_W2, false, BFX>(a, B, max_cols, s);
         else launch_da_inst<ACT_SNAKE, 0, NTT, DA_W2, false, BFX>(a, B, max_cols, s);
     } else if (a.act == ACT_LEAKY) {

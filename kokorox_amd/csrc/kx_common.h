@@ -106,7 +106,6 @@ struct ConvArgs {
     const void* w16b;  // the bf16 form of the same image (prec1 == 2 launches of the direct-A kernel swap it in), or null
     const void* w8x;   // f16f8 mode (CONV_F16F8): the 8-bit image of the weights' cross-term operands (launch_pack_conv8x), or null
     int epi_stream;    // the direct-A kernels' interior stores and residual loads non-temporal (the output tensor is far beyond L2 + MALL)
-    int hwcos;         // f16f8 mode: the 3-tap snake convs of the direct-A kernel take sin^2 from the hardware cosine (the F8 forms always do)
     int n_chunks16;
     float w_unscale;
     float x_prescale;  // f16x3: power of two applied to the transformed input before the hi/lo split (w_unscale carries

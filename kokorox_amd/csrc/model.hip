@@ -654,7 +654,6 @@ void Model::conv(const ConvW& w, const T& in, const T& out, const ConvOpts& o) {
     a.w16b = w.w16b;
     // f16f8 mode (opt-in): the layers that carry an 8-bit cross image run two MFMA-equivalents per product instead of three
     a.w8x = conv_mode == CONV_F16F8 ? w.w8x : nullptr;
-    a.hwcos = conv_mode == CONV_F16F8 && o.act == ACT_SNAKE && w.K == 3 && w.BM == 128;
     // outputs that no cache can hold until the next layer reads them (> 512 MB: L2 is 32 MB, MALL 256 MB) are streamed by the direct-A
     // kernels' interior stores (non-temporal stores and residual loads); smaller ones (small batches, the token axis, the decoder)
     // stay cacheable
@@ -1026,11 +1025,14 @@ void Model::set_conv_mode(int mode) {
         KX_HIP(hipStreamSynchronize(stream_));
     }
     if (mode == CONV_F16F8) {
-        // 8-bit cross images of the layers the f16f8 kernels take (the S16 form's shapes: 7- and 11-tap snake convs), once
+        // 8-bit cross images of the layers the f16f8 kernels take (7- and 11-tap convs, and the 3-tap ones of at most 256 rows: the
+        // generator's snake resblocks -- the activation is a property of the call, not of the weights, so a few leaky 3-tap convs of
+        // the predictor get an image they never use), once
         KX_HIP(hipSetDevice(device));
         for (auto& kv : convs_) {
             ConvW& c = kv.second;
-            if (c.w8x || !c.w16 || c.BM != 128 || c.up_s || !(c.K == 7 || c.K == 11) || c.n_chunks16 < 2 || (c.n_chunks16 & 1)) continue;
+            const bool taps = c.K == 7 || c.K == 11 || (c.K == 3 && c.rows <= 256 && conv16_da_f8_shape(3, 1));
+            if (c.w8x || !c.w16 || c.BM != 128 || c.up_s || !taps || c.n_chunks16 < 2 || (c.n_chunks16 & 1)) continue;
             void* p = nullptr;
             KX_HIP(hipMalloc(&p, packed_conv8x_bytes(c.rows, c.Cin, c.K)));
             owned_.push_back(p);

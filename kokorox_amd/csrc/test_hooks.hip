@@ -235,7 +235,6 @@ static int test_conv1d_impl(int device_id, const float* x, int B, int Cin, int L
                 void* p8 = dm.get<unsigned char>(kx::packed_conv8x_bytes(rows, Cin, k));
                 kx::launch_pack_conv8x(p16, p8, rows, Cin, k, nullptr);
                 a.w8x = p8;
-                a.hwcos = act == kx::ACT_SNAKE && k == 3;
             }
             a.n_chunks16 = (Cin + 15) / 16;
             a.w_unscale = std::ldexp(1.0f, -ws);

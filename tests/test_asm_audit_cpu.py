@@ -146,8 +146,7 @@ def test_direct_a_conv_assembly(tmp_path, src):
     assert ks, "no kernel found"
     # every instantiation launch_da_ntt can select, both tile widths; the four unrolled 256-column forms of the 2 x 2 layout
     # (the reduced-precision unit holds every form twice since round 5: f16 and bf16 operands)
-    # (round 5: + the hardware-cosine forms of the 3-tap snake convs, two tile widths in the main unit, one in the 2 x 2 unit)
-    assert len(ks) == {"conv_f16x3_da_w2.hip": 5, "conv_f16x3_da_s16.hip": 4, "conv_f16x3_da_p1.hip": 28}.get(src, 16), sorted(ks)
+    assert len(ks) == {"conv_f16x3_da_w2.hip": 4, "conv_f16x3_da_s16.hip": 4, "conv_f16x3_da_p1.hip": 28}.get(src, 14), sorted(ks)
     for name, lines in ks.items():
         _audit_spills(name, lines)
         bad = _audit_no_touch_before_wait(lines)
@@ -218,12 +217,12 @@ def test_f16f8_conv_assembly(tmp_path):
     independent restatement of the schedule, no ring register is touched before its wait, and the MFMA mix is 2 f16 per block plus
     2 scaled per block of a cross-term pair-step."""
     ks = _kernels(_asm("conv_f16x3_da_f8.hip", tmp_path))
-    assert len(ks) == 4, sorted(ks)
+    assert len(ks) == 6, sorted(ks)
     for name, lines in ks.items():
         m = re.search(r"da_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb0ELb0ELb1ELb0ELb0ELb1E", name)
         assert m, name
         act, kt, ntt = (int(x) for x in m.groups())
-        assert act == 2 and kt in (7, 11) and ntt in (4, 6)
+        assert act == 2 and kt in (3, 7, 11) and ntt in (4, 6)
         mf = [i for i, ln in enumerate(lines) if "v_mfma" in ln]
         body = lines[mf[0]:mf[-1] + 1]
         assert not any("scratch_" in ln for ln in body), f"{name} spills inside the main loop"
@@ -267,7 +266,7 @@ def test_f16f8_conv_assembly(tmp_path):
         valu = sum(1 for ln in body if re.match(r"\s*v_(?!mfma)", ln))
         # vector instructions per matrix-pipe slot of 16 cycles (a scaled MFMA is two): the loop is bound by the SIMD's vector issue
         # as much as by the matrix pipe, so this must not quietly grow
-        assert valu / (n16 + 2 * n8) <= {11: 2.0, 7: 3.0}[kt], (name, valu / (n16 + 2 * n8))
+        assert valu / (n16 + 2 * n8) <= {11: 2.0, 7: 3.0, 3: 6.5}[kt], (name, valu / (n16 + 2 * n8))
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
