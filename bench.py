@@ -116,7 +116,7 @@ def roofline(f16x3, conv_flops, conv_ms, n_launch, steps, wall, B, T, F, conv_by
             else "kx::conv1d_mfma_kernel<128,128,2,2> (f32 32x32x2 MFMA implicit GEMM)")
     if f8:
         kern = ("kx::conv1d_f16x3_da_kernel<ACT,K,NT,P1,W2,S16,PRE,BF,F8> + kx::conv1d_f16x3_dag_kernel + kx::conv1d_f16x3_kernel<128,..> (the "
-                "128-row conv family, implicit GEMM; f16f8 mode: the 7 / 11-tap convs = 64 % of the family's FLOPs run v_mfma_f32_16x16x32_f16 "
+                "128-row conv family, implicit GEMM; f16f8 mode: the generator's 3 / 7 / 11-tap snake convs = 88 % of the family's FLOPs run v_mfma_f32_16x16x32_f16 "
                 "for a_hi b_hi + v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3) for the two cross terms = 2 MFMA-equivalents per product, the rest 3 "
                 "f16 MFMAs per product)")
     traffic, traffic_src = pmc_traffic(B, T, F, "f16f8" if f8 else ("f16x3" if f16x3 else "f32"))

@@ -191,7 +191,7 @@ int kx_arena_bytes(kx_model* m, int64_t* out3);
  * products), 1 = f16x3 split MFMA (three v_mfma_f32_32x32x16_f16 per K-step on hi/lo halves, ~22
  * significant bits per product, f32 accumulation; env KOKOROX_CONV=f16x3).  Env KOKOROX_CONV=f32 selects 0 at create.
  * 6 = f16f8, the DEFAULT since round 5 (env KOKOROX_CONV=f16f8): mode 1, except that the snake convs of the generator (3, 7 and 11
- * taps: 70 % of the forward's multiply-adds) carry the two cross terms of the split product, a_lo b_hi + a_hi b_lo, on the 8-bit
+ * taps: 85 % of the forward's multiply-adds) carry the two cross terms of the split product, a_lo b_hi + a_hi b_lo, on the 8-bit
  * scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4 on e4m3 images of the four operands) and a_hi b_hi on v_mfma_f32_16x16x32_f16:
  * two MFMA-equivalents per product instead of three, ~17 significant bits per product instead of 22 (measured 1e-5 relative per
  * conv output; the waveform moves by < 1e-5 against mode 1), inside the 1e-4 parity band by the same protocol as modes 0 and 1
