@@ -782,7 +782,14 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
 #ifndef KX_F8_I0B
 #define KX_F8_I0B 8
 #endif
-        constexpr int I0A = (KT >= 9 ? KX_F8_I0A_LONG : (KT >= 5 ? KX_F8_I0A_MID : 4)) * NT / 8, I0B = (KT >= 5 ? KX_F8_I0B : 2) * NT / 8;
+#ifndef KX_F8_I0A_SHORT
+#define KX_F8_I0A_SHORT 4
+#endif
+#ifndef KX_F8_I0B_SHORT
+#define KX_F8_I0B_SHORT 2
+#endif
+        constexpr int I0A = (KT >= 9 ? KX_F8_I0A_LONG : (KT >= 5 ? KX_F8_I0A_MID : KX_F8_I0A_SHORT)) * NT / 8,
+                      I0B = (KT >= 5 ? KX_F8_I0B : KX_F8_I0B_SHORT) * NT / 8;
         static_assert(I0A < NA && I0B < NA, "f16f8: the transform needs blocks to ride on");
 #ifndef KX_F8_G
 #define KX_F8_G 2
