@@ -46,6 +46,9 @@
 #include <type_traits>
 
 
+#ifndef KX_F8_RAW_AUX
+#define KX_F8_RAW_AUX 0  // cache policy of the F8 forms' input prefetch (2 = non-temporal: measured, see profiles/r05_f16f8_form.txt)
+#endif
 #ifndef KX_F8_HWCOS
 #define KX_F8_HWCOS 1  // f16f8 forms: the snake's sin^2 on v_cos_f32 (0: the polynomial of the other forms)
 #endif
@@ -367,14 +370,14 @@ __global__ __launch_bounds__(256, (NTT == 8 || S16) ? 2 : 3) void conv1d_f16x3_d
                 const int ci = ch * CK16 + g * 8 + c;
                 const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(ci < cmax_in ? ci : cmax_in) * (4u * (unsigned)a.x_ld);
 #pragma unroll
-                for (int j = 0; j < NJF; ++j) raw[j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrow, 4u * (unsigned)xoff[j], so, 0));
+                for (int j = 0; j < NJF; ++j) raw[j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrow, 4u * (unsigned)xoff[j], so, KX_F8_RAW_AUX));
             }
             if constexpr (SPLIT) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int ci = ch * CK16 + g * 8 + jb * 4 + c;
                     const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(ci < cmax_in ? ci : cmax_in) * (4u * (unsigned)a.x_ld);
-                    raw[NJF][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrow, 4u * (unsigned)xoff[NJF], so, 0));
+                    raw[NJF][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrow, 4u * (unsigned)xoff[NJF], so, KX_F8_RAW_AUX));
                 }
             }
             return;
