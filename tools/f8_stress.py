@@ -1,7 +1,7 @@
 """Determinism of the forward under memory contention: the ring loads of the direct-A kernels are waited for by hand-counted
 s_waitcnt vmcnt(N); a wrong count would hand on a stale fragment only when memory is slow.  A background stream keeps HBM busy with
 large copies while the same batch is run again and again: every run must give the bits of the first.
-usage: python tools/f8_stress.py [runs]   (on the GPU box; ~20 s)"""
+usage: python tools/f8_stress.py [runs] [batch]   (on the GPU box; ~20 s; batch 1 .. 2 exercises the small-grid tile forms)"""
 import os
 import sys
 import threading
@@ -19,7 +19,7 @@ from oracle import kokoro_ref as R  # noqa: E402  (inputs only)
 def main():
     runs = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     m = hk.HipKoko.new(W.ensure_synthetic_blob())
-    B = 16
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
     ids = R.synthetic_inputs(B, 128, seed=0)
     voices = W.synthetic_voices(4)
     styles = [voices[b % 4, 128, 0] for b in range(B)]
